@@ -1,0 +1,909 @@
+/*
+ * falcon_oracle.c -- CPU restatement of falcon's K / f_int assembly hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see falcon_oracle.h).  PARITY UNPINNED: no reference
+ * fixture pins these numbers; analytic KATs in tests/ do.
+ *
+ * The loop structure follows the reference on purpose (element-serial, Gauss
+ * point inner loop, dense B^T D B, per-entry search scatter into CSR) so the
+ * same code doubles as the timed single-core CPU baseline.
+ *
+ * Reference files restated (paths under /root/reference):
+ *   src/fem/solidmech/LinearElasticityModel.cpp:297-430
+ *   src/fem/solidmech/PhaseFractureModel.cpp:279-361,502-751
+ *   src/fem/solidmech/PhaseFractureExtModel.cpp:488-774
+ *   src/fem/solidmech/PhaseFractureExtItModel.cpp:518-797
+ *   src/materials/HookeMaterial.cpp:152-166,202-267
+ *   src/materials/AmorPhaseMaterial.cpp:77-150,200-232
+ *   src/materials/BourdinPhaseMaterial.cpp:131-145
+ *   src/materials/MiehePhaseMaterial.cpp:80-149,200-258,342-406
+ *   src/util/ShapeUtils.cpp:73-145, TensorUtils.cpp, MathUtils.cpp:23-41, Constants.cpp:9
+ */
+#include "falcon_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXNPE 20
+#define MAXNIP 27
+#define MAXSTR 6
+#define MAXND  (3 * MAXNPE)
+
+static char g_err[512] = "";
+const char* fo_last_error(void) { return g_err; }
+#define FAIL(...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return -1; } while (0)
+
+/* src/util/Constants.cpp:9 */
+static const int STRAIN_COUNTS[4] = { 0, 1, 4, 6 };
+
+/* ------------------------------------------------------------------------- */
+/* Shapes (Jive IShape stand-in; standard isoparametric definitions)         */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+  int    rank, npe, nip;
+  double N [MAXNIP][MAXNPE];
+  double dN[MAXNIP][MAXNPE][3];
+  double w [MAXNIP];
+} shape_t;
+
+static void gauss1d(int n, double* x, double* w) {
+  if (n == 1) { x[0] = 0.0; w[0] = 2.0; }
+  else if (n == 2) { x[0] = -1.0 / sqrt(3.0); x[1] = 1.0 / sqrt(3.0); w[0] = w[1] = 1.0; }
+  else { x[0] = -sqrt(0.6); x[1] = 0.0; x[2] = sqrt(0.6); w[0] = w[2] = 5.0 / 9.0; w[1] = 8.0 / 9.0; }
+}
+
+/* perimeter orderings (corner-mid-corner-mid), SURVEY 8c */
+static const double Q4X[4][2] = { {-1,-1},{1,-1},{1,1},{-1,1} };
+static const double Q8X[8][2] = { {-1,-1},{0,-1},{1,-1},{1,0},{1,1},{0,1},{-1,1},{-1,0} };
+static const double H8X[8][3] = { {-1,-1,-1},{1,-1,-1},{1,1,-1},{-1,1,-1},
+                                  {-1,-1, 1},{1,-1, 1},{1,1, 1},{-1,1, 1} };
+/* bottom perimeter (8), vertical mid-edges (4), top perimeter (8) */
+static const double H20X[20][3] = {
+  {-1,-1,-1},{0,-1,-1},{1,-1,-1},{1,0,-1},{1,1,-1},{0,1,-1},{-1,1,-1},{-1,0,-1},
+  {-1,-1,0},{1,-1,0},{1,1,0},{-1,1,0},
+  {-1,-1,1},{0,-1,1},{1,-1,1},{1,0,1},{1,1,1},{0,1,1},{-1,1,1},{-1,0,1} };
+
+static void eval_tri3(double x, double y, double* N, double (*d)[3]) {
+  N[0] = 1.0 - x - y; N[1] = x; N[2] = y;
+  d[0][0] = -1; d[0][1] = -1; d[1][0] = 1; d[1][1] = 0; d[2][0] = 0; d[2][1] = 1;
+}
+static void eval_tri6(double x, double y, double* N, double (*d)[3]) {
+  double L1 = 1.0 - x - y, L2 = x, L3 = y;
+  /* dL1 = (-1,-1), dL2 = (1,0), dL3 = (0,1) */
+  N[0] = L1 * (2 * L1 - 1); d[0][0] = -(4 * L1 - 1); d[0][1] = -(4 * L1 - 1);
+  N[1] = 4 * L1 * L2;       d[1][0] = 4 * (L1 - L2);  d[1][1] = -4 * L2;
+  N[2] = L2 * (2 * L2 - 1); d[2][0] = 4 * L2 - 1;     d[2][1] = 0;
+  N[3] = 4 * L2 * L3;       d[3][0] = 4 * L3;         d[3][1] = 4 * L2;
+  N[4] = L3 * (2 * L3 - 1); d[4][0] = 0;              d[4][1] = 4 * L3 - 1;
+  N[5] = 4 * L3 * L1;       d[5][0] = -4 * L3;        d[5][1] = 4 * (L1 - L3);
+}
+static void eval_quad4(double x, double y, double* N, double (*d)[3]) {
+  for (int a = 0; a < 4; a++) {
+    double xa = Q4X[a][0], ya = Q4X[a][1];
+    N[a] = 0.25 * (1 + xa * x) * (1 + ya * y);
+    d[a][0] = 0.25 * xa * (1 + ya * y);
+    d[a][1] = 0.25 * ya * (1 + xa * x);
+  }
+}
+static void eval_quad8(double x, double y, double* N, double (*d)[3]) {
+  for (int a = 0; a < 8; a++) {
+    double xa = Q8X[a][0], ya = Q8X[a][1];
+    if (xa != 0 && ya != 0) {
+      N[a] = 0.25 * (1 + xa * x) * (1 + ya * y) * (xa * x + ya * y - 1);
+      d[a][0] = 0.25 * xa * (1 + ya * y) * (2 * xa * x + ya * y);
+      d[a][1] = 0.25 * ya * (1 + xa * x) * (xa * x + 2 * ya * y);
+    } else if (xa == 0) {
+      N[a] = 0.5 * (1 - x * x) * (1 + ya * y);
+      d[a][0] = -x * (1 + ya * y);
+      d[a][1] = 0.5 * ya * (1 - x * x);
+    } else {
+      N[a] = 0.5 * (1 + xa * x) * (1 - y * y);
+      d[a][0] = 0.5 * xa * (1 - y * y);
+      d[a][1] = -y * (1 + xa * x);
+    }
+  }
+}
+static void eval_hex8(double x, double y, double z, double* N, double (*d)[3]) {
+  for (int a = 0; a < 8; a++) {
+    double xa = H8X[a][0], ya = H8X[a][1], za = H8X[a][2];
+    N[a] = 0.125 * (1 + xa * x) * (1 + ya * y) * (1 + za * z);
+    d[a][0] = 0.125 * xa * (1 + ya * y) * (1 + za * z);
+    d[a][1] = 0.125 * ya * (1 + xa * x) * (1 + za * z);
+    d[a][2] = 0.125 * za * (1 + xa * x) * (1 + ya * y);
+  }
+}
+static void eval_hex20(double x, double y, double z, double* N, double (*d)[3]) {
+  for (int a = 0; a < 20; a++) {
+    double xa = H20X[a][0], ya = H20X[a][1], za = H20X[a][2];
+    if (xa != 0 && ya != 0 && za != 0) {
+      double s = xa * x + ya * y + za * z - 2;
+      double fx = 1 + xa * x, fy = 1 + ya * y, fz = 1 + za * z;
+      N[a] = 0.125 * fx * fy * fz * s;
+      d[a][0] = 0.125 * xa * fy * fz * (s + fx);
+      d[a][1] = 0.125 * ya * fx * fz * (s + fy);
+      d[a][2] = 0.125 * za * fx * fy * (s + fz);
+    } else if (xa == 0) {
+      N[a] = 0.25 * (1 - x * x) * (1 + ya * y) * (1 + za * z);
+      d[a][0] = -0.5 * x * (1 + ya * y) * (1 + za * z);
+      d[a][1] = 0.25 * ya * (1 - x * x) * (1 + za * z);
+      d[a][2] = 0.25 * za * (1 - x * x) * (1 + ya * y);
+    } else if (ya == 0) {
+      N[a] = 0.25 * (1 + xa * x) * (1 - y * y) * (1 + za * z);
+      d[a][0] = 0.25 * xa * (1 - y * y) * (1 + za * z);
+      d[a][1] = -0.5 * y * (1 + xa * x) * (1 + za * z);
+      d[a][2] = 0.25 * za * (1 + xa * x) * (1 - y * y);
+    } else {
+      N[a] = 0.25 * (1 + xa * x) * (1 + ya * y) * (1 - z * z);
+      d[a][0] = 0.25 * xa * (1 + ya * y) * (1 - z * z);
+      d[a][1] = 0.25 * ya * (1 + xa * x) * (1 - z * z);
+      d[a][2] = -0.5 * z * (1 + xa * x) * (1 + ya * y);
+    }
+  }
+}
+
+static int shape_init(shape_t* s, int id) {
+  memset(s, 0, sizeof *s);
+  double gx[3], gw[3];
+  switch (id) {
+    case FO_TRI3_G1: case FO_TRI3_G3: case FO_TRI6_G3: {
+      s->rank = 2; s->npe = (id == FO_TRI6_G3) ? 6 : 3;
+      double px[3][2]; double pw[3];
+      if (id == FO_TRI3_G1) { s->nip = 1; px[0][0] = px[0][1] = 1.0 / 3.0; pw[0] = 0.5; }
+      else { s->nip = 3;
+             px[0][0] = 1.0 / 6.0; px[0][1] = 1.0 / 6.0;
+             px[1][0] = 2.0 / 3.0; px[1][1] = 1.0 / 6.0;
+             px[2][0] = 1.0 / 6.0; px[2][1] = 2.0 / 3.0;
+             pw[0] = pw[1] = pw[2] = 1.0 / 6.0; }
+      for (int ip = 0; ip < s->nip; ip++) {
+        if (s->npe == 3) eval_tri3(px[ip][0], px[ip][1], s->N[ip], s->dN[ip]);
+        else             eval_tri6(px[ip][0], px[ip][1], s->N[ip], s->dN[ip]);
+        s->w[ip] = pw[ip];
+      }
+      return 0;
+    }
+    case FO_QUAD4_G2: case FO_QUAD8_G3: case FO_QUAD8_G2: {
+      int n = (id == FO_QUAD8_G3) ? 3 : 2;
+      s->rank = 2; s->npe = (id == FO_QUAD4_G2) ? 4 : 8; s->nip = n * n;
+      gauss1d(n, gx, gw);
+      for (int iy = 0; iy < n; iy++) for (int ix = 0; ix < n; ix++) {
+        int ip = iy * n + ix;
+        if (s->npe == 4) eval_quad4(gx[ix], gx[iy], s->N[ip], s->dN[ip]);
+        else             eval_quad8(gx[ix], gx[iy], s->N[ip], s->dN[ip]);
+        s->w[ip] = gw[ix] * gw[iy];
+      }
+      return 0;
+    }
+    case FO_HEX8_G2: case FO_HEX20_G3: case FO_HEX20_G2: {
+      int n = (id == FO_HEX20_G3) ? 3 : 2;
+      s->rank = 3; s->npe = (id == FO_HEX8_G2) ? 8 : 20; s->nip = n * n * n;
+      gauss1d(n, gx, gw);
+      for (int iz = 0; iz < n; iz++) for (int iy = 0; iy < n; iy++) for (int ix = 0; ix < n; ix++) {
+        int ip = (iz * n + iy) * n + ix;
+        if (s->npe == 8) eval_hex8 (gx[ix], gx[iy], gx[iz], s->N[ip], s->dN[ip]);
+        else             eval_hex20(gx[ix], gx[iy], gx[iz], s->N[ip], s->dN[ip]);
+        s->w[ip] = gw[ix] * gw[iy] * gw[iz];
+      }
+      return 0;
+    }
+  }
+  FAIL("unknown shape id %d", id);
+}
+
+int fo_shape_info_get(int shape, fo_shape_info* out) {
+  shape_t s;
+  if (shape_init(&s, shape)) return -1;
+  out->rank = s.rank; out->npe = s.npe; out->nip = s.nip; out->str = STRAIN_COUNTS[s.rank];
+  return 0;
+}
+
+int fo_shape_tables(int shape, double* N, double* dN, double* w) {
+  shape_t s;
+  if (shape_init(&s, shape)) return -1;
+  for (int ip = 0; ip < s.nip; ip++) {
+    w[ip] = s.w[ip];
+    for (int a = 0; a < s.npe; a++) {
+      N[ip * s.npe + a] = s.N[ip][a];
+      for (int k = 0; k < s.rank; k++) dN[(ip * s.npe + a) * s.rank + k] = s.dN[ip][a][k];
+    }
+  }
+  return 0;
+}
+
+/* IShape::getShapeGradients stand-in: grads[ip][a][i] = dN_a/dx_i, wip = w * det J */
+static int shape_gradients(const shape_t* s, const double (*x)[3],
+                           double grads[MAXNIP][MAXNPE][3], double* wip) {
+  const int r = s->rank;
+  for (int ip = 0; ip < s->nip; ip++) {
+    double J[3][3] = { {0} };      /* J[i][k] = sum_a x_a[i] dN_a/dxi_k */
+    for (int a = 0; a < s->npe; a++)
+      for (int i = 0; i < r; i++)
+        for (int k = 0; k < r; k++) J[i][k] += x[a][i] * s->dN[ip][a][k];
+    double det, inv[3][3];
+    if (r == 2) {
+      det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+      inv[0][0] =  J[1][1] / det; inv[0][1] = -J[0][1] / det;
+      inv[1][0] = -J[1][0] / det; inv[1][1] =  J[0][0] / det;
+    } else {
+      double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+      double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+      double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+      det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+      inv[0][0] = c00 / det;
+      inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+      inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+      inv[1][0] = c01 / det;
+      inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+      inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+      inv[2][0] = c02 / det;
+      inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+      inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+    }
+    if (!(det > 0.0)) FAIL("non-positive Jacobian determinant %g", det);
+    /* dN/dx_i = sum_k dN/dxi_k * inv[k][i]   (inv = J^{-1}: dxi_k/dx_i) */
+    for (int a = 0; a < s->npe; a++)
+      for (int i = 0; i < r; i++) {
+        double g = 0.0;
+        for (int k = 0; k < r; k++) g += s->dN[ip][a][k] * inv[k][i];
+        grads[ip][a][i] = g;
+      }
+    wip[ip] = s->w[ip] * det;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* B matrix: src/util/ShapeUtils.cpp:73-104 (2D, 4 rows) and :114-145 (3D)    */
+/* b is str x nd, row-major here: b[c*nd + col]                              */
+/* ------------------------------------------------------------------------- */
+static void fill_B(int rank, int npe, const double g[MAXNPE][3], double* b) {
+  const int nd = rank * npe;
+  const int str = STRAIN_COUNTS[rank];
+  memset(b, 0, sizeof(double) * str * nd);
+  if (rank == 2) {
+    for (int a = 0; a < npe; a++) {
+      int i = 2 * a, i1 = i + 1;
+      b[0 * nd + i ] = g[a][0];
+      b[1 * nd + i1] = g[a][1];
+      b[3 * nd + i ] = g[a][1];
+      b[3 * nd + i1] = g[a][0];
+    }
+  } else {
+    for (int a = 0; a < npe; a++) {
+      int i = 3 * a;
+      b[0 * nd + i + 0] = g[a][0];
+      b[1 * nd + i + 1] = g[a][1];
+      b[2 * nd + i + 2] = g[a][2];
+      b[3 * nd + i + 0] = g[a][1];
+      b[3 * nd + i + 1] = g[a][0];
+      b[4 * nd + i + 1] = g[a][2];
+      b[4 * nd + i + 2] = g[a][1];
+      b[5 * nd + i + 2] = g[a][0];
+      b[5 * nd + i + 0] = g[a][2];
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Materials                                                                 */
+/* ------------------------------------------------------------------------- */
+
+/* HookeMaterial::computeStiffMat_, src/materials/HookeMaterial.cpp:202-267 */
+static int hooke_stiff(int rank, int state, double e, double nu, double* D /* str*str */) {
+  const int n = STRAIN_COUNTS[rank];
+  memset(D, 0, sizeof(double) * n * n);
+#define S(i, j) D[(i) * n + (j)]
+  if (rank == 3) {
+    const double a = e / ((1.0 + nu) * (1.0 - 2.0 * nu));
+    const double b = 0.5 * (1.0 - 2.0 * nu);
+    const double c = 1.0 - nu;
+    S(0,0) = a * c;
+    S(0,1) = S(0,2) = a * nu;
+    S(1,1) = S(0,0);
+    S(1,2) = S(0,1);
+    S(2,2) = S(0,0);
+    S(3,3) = a * b;
+    S(4,4) = S(3,3);
+    S(5,5) = S(3,3);
+    for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) S(i,j) = S(j,i);
+  } else if (rank == 2 && state == FO_PLANE_STRAIN) {
+    const double a = e / ((1.0 + nu) * (1.0 - 2.0 * nu));
+    const double b = 0.5 * (1.0 - 2.0 * nu);
+    const double c = 1.0 - nu;
+    S(0,0) = a * c;
+    S(0,1) = S(1,0) = a * nu;
+    S(0,2) = a * nu;
+    S(1,1) = a * c;
+    S(1,2) = a * nu;
+    S(3,3) = a * b;
+    S(2,0) = a * nu; S(2,1) = a * nu; S(2,2) = a * c;
+  } else if (rank == 2 && state == FO_PLANE_STRESS) {
+    const double a = e / (1.0 - nu * nu);
+    S(0,0) = a;
+    S(0,1) = S(1,0) = a * nu;
+    S(1,1) = a;
+    S(3,3) = a * 0.5 * (1.0 - nu);
+  } else {
+    FAIL("hooke: unexpected rank/state %d/%d", rank, state);
+  }
+#undef S
+  return 0;
+}
+
+static void matvec(int n, const double* A, const double* x, double* y) {
+  for (int i = 0; i < n; i++) {
+    double s = 0.0;
+    for (int j = 0; j < n; j++) s += A[i * n + j] * x[j];
+    y[i] = s;
+  }
+}
+static double dotn(int n, const double* a, const double* b) {
+  double s = 0.0;
+  for (int i = 0; i < n; i++) s += a[i] * b[i];
+  return s;
+}
+
+/* src/util/MathUtils.cpp:23-41 */
+static double macaulayP(double x) { return 0.5 * (x + fabs(x)); }
+static double macaulayN(double x) { return 0.5 * (x - fabs(x)); }
+static double heavisideP(double x) { return (x < 0.) ? 0.0 : 1.0; }
+
+/* AmorPhaseMaterial::update, src/materials/AmorPhaseMaterial.cpp:200-232 (+ configure :85-148) */
+static void amor_update(int rank, double E, double nu, const double* strain, double gphi,
+                        double* stress, double* stiff, double* psi, double* stressP) {
+  const int n = STRAIN_COUNTS[rank];
+  const double K = E / (3.0 * (1.0 - 2.0 * nu));
+  const double G = E / (2.0 * (1.0 + nu));
+  double PVol[MAXSTR * MAXSTR] = { 0 }, PDev[MAXSTR * MAXSTR] = { 0 };
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    PVol[i * n + j] = 1.0;
+    PDev[i * n + j] = (i == j) ? 2.0 / 3.0 : -1.0 / 3.0;
+  }
+  for (int i = 3; i < n; i++) PDev[i * n + i] = 0.5;
+
+  double tr = strain[0] + strain[1] + strain[2];
+  for (int i = 0; i < n * n; i++) stiff[i] = 2.0 * G * PDev[i];
+  if (tr > 0.0) for (int i = 0; i < n * n; i++) stiff[i] += K * PVol[i];
+  matvec(n, stiff, strain, stressP);
+  *psi = 0.5 * dotn(n, stressP, strain);
+  for (int i = 0; i < n * n; i++) stiff[i] *= gphi;
+  if (tr <= 0.0) for (int i = 0; i < n * n; i++) stiff[i] += K * PVol[i];
+  matvec(n, stiff, strain, stress);
+}
+
+/* BourdinPhaseMaterial::update, src/materials/BourdinPhaseMaterial.cpp:131-145 */
+static int bourdin_update(int rank, int state, double E, double nu, const double* strain, double gphi,
+                          double* stress, double* stiff, double* psi, double* stressP) {
+  const int n = STRAIN_COUNTS[rank];
+  double D[MAXSTR * MAXSTR];
+  if (hooke_stiff(rank, state, E, nu, D)) return -1;
+  matvec(n, D, strain, stressP);
+  *psi = 0.5 * dotn(n, stressP, strain);
+  for (int i = 0; i < n; i++) stress[i] = gphi * stressP[i];
+  for (int i = 0; i < n * n; i++) stiff[i] = gphi * D[i];
+  return 0;
+}
+
+/* jem::numeric::EigenUtils::symSolve stand-in: cyclic Jacobi on a 3x3 symmetric matrix.
+ * (Jem's algorithm is not visible; P+ depends only on eigen-spaces, not on the solver.) */
+static void sym_eig3(const double A[3][3], double* val, double V[3][3]) {
+  double a[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { a[i][j] = A[i][j]; V[i][j] = (i == j); }
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    double dia = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+    if (off <= 1e-300 || off <= 1e-34 * dia) break;
+    for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
+      if (a[p][q] == 0.0) continue;
+      double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+      double t = ((theta >= 0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+      for (int k = 0; k < 3; k++) {          /* A <- A J */
+        double akp = a[k][p], akq = a[k][q];
+        a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq;
+      }
+      for (int k = 0; k < 3; k++) {          /* A <- J^T A */
+        double apk = a[p][k], aqk = a[q][k];
+        a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk;
+      }
+      for (int k = 0; k < 3; k++) {          /* V <- V J */
+        double vkp = V[k][p], vkq = V[k][q];
+        V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+      }
+    }
+  }
+  for (int i = 0; i < 3; i++) val[i] = a[i][i];
+}
+
+typedef double quad4_t[3][3][3][3];
+
+/* tensorUtils::tensor2voigt, src/util/TensorUtils.cpp:304-398 (verbatim incl. the
+ * duplicated-term shear-shear entries of the 3D branch, :368-369,378-379,388-389) */
+static void tensor2voigt(quad4_t A, int strCount, double* M) {
+  const int n = strCount;
+  memset(M, 0, sizeof(double) * n * n);
+#define MM(i, j) M[(i) * n + (j)]
+  if (n == 4) {
+    MM(0,0) = A[0][0][0][0]; MM(1,0) = A[1][1][0][0]; MM(2,0) = A[2][2][0][0];
+    MM(3,0) = 0.5 * (A[0][1][0][0] + A[1][0][0][0]);
+    MM(0,1) = A[0][0][1][1]; MM(1,1) = A[1][1][1][1]; MM(2,1) = A[2][2][1][1];
+    MM(3,1) = 0.5 * (A[0][1][1][1] + A[1][0][1][1]);
+    MM(0,2) = A[0][0][2][2]; MM(1,2) = A[1][1][2][2]; MM(2,2) = A[2][2][2][2];
+    MM(3,2) = 0.5 * (A[0][1][2][2] + A[1][0][2][2]);
+    MM(0,3) = 0.5 * (A[0][0][0][1] + A[0][0][1][0]);
+    MM(1,3) = 0.5 * (A[1][1][0][1] + A[1][1][1][0]);
+    MM(2,3) = 0.5 * (A[2][2][0][1] + A[2][2][1][0]);
+    MM(3,3) = 0.25 * (A[0][1][0][1] + A[1][0][0][1] + A[0][1][1][0] + A[1][0][1][0]);
+  } else {
+    MM(0,0) = A[0][0][0][0]; MM(1,0) = A[1][1][0][0]; MM(2,0) = A[2][2][0][0];
+    MM(3,0) = 0.5 * (A[0][1][0][0] + A[1][0][0][0]);
+    MM(4,0) = 0.5 * (A[1][2][0][0] + A[2][1][0][0]);
+    MM(5,0) = 0.5 * (A[2][0][0][0] + A[0][2][0][0]);
+    MM(0,1) = A[0][0][1][1]; MM(1,1) = A[1][1][1][1]; MM(2,1) = A[2][2][1][1];
+    MM(3,1) = 0.5 * (A[0][1][1][1] + A[1][0][1][1]);
+    MM(4,1) = 0.5 * (A[1][2][1][1] + A[2][1][1][1]);
+    MM(5,1) = 0.5 * (A[2][0][1][1] + A[0][2][1][1]);
+    MM(0,2) = A[0][0][2][2]; MM(1,2) = A[1][1][2][2]; MM(2,2) = A[2][2][2][2];
+    MM(3,2) = 0.5 * (A[0][1][2][2] + A[1][0][2][2]);
+    MM(4,2) = 0.5 * (A[1][2][2][2] + A[2][1][2][2]);
+    MM(5,2) = 0.5 * (A[2][0][2][2] + A[0][2][2][2]);
+    MM(0,3) = 0.5 * (A[0][0][0][1] + A[0][0][1][0]);
+    MM(1,3) = 0.5 * (A[1][1][0][1] + A[1][1][1][0]);
+    MM(2,3) = 0.5 * (A[2][2][0][1] + A[2][2][1][0]);
+    MM(3,3) = 0.25 * (A[0][1][0][1] + A[1][0][1][0] + A[0][1][0][1] + A[1][0][1][0]);
+    MM(4,3) = 0.25 * (A[1][2][0][1] + A[2][1][1][0] + A[2][1][0][1] + A[1][2][1][0]);
+    MM(5,3) = 0.25 * (A[0][2][0][1] + A[2][0][1][0] + A[2][0][0][1] + A[0][2][1][0]);
+    MM(0,4) = 0.5 * (A[0][0][1][2] + A[0][0][2][1]);
+    MM(1,4) = 0.5 * (A[1][1][1][2] + A[1][1][2][1]);
+    MM(2,4) = 0.5 * (A[2][2][1][2] + A[2][2][2][1]);
+    MM(3,4) = 0.25 * (A[0][1][1][2] + A[1][0][2][1] + A[0][1][1][2] + A[1][0][2][1]);
+    MM(4,4) = 0.25 * (A[1][2][1][2] + A[2][1][2][1] + A[2][1][1][2] + A[1][2][2][1]);
+    MM(5,4) = 0.25 * (A[0][2][1][2] + A[2][0][2][1] + A[2][0][1][2] + A[0][2][2][1]);
+    MM(0,5) = 0.5 * (A[0][0][0][2] + A[0][0][2][0]);
+    MM(1,5) = 0.5 * (A[1][1][0][2] + A[1][1][2][0]);
+    MM(2,5) = 0.5 * (A[2][2][0][2] + A[2][2][2][0]);
+    MM(3,5) = 0.25 * (A[0][1][0][2] + A[1][0][2][0] + A[0][1][0][2] + A[1][0][2][0]);
+    MM(4,5) = 0.25 * (A[1][2][0][2] + A[2][1][2][0] + A[2][1][0][2] + A[1][2][2][0]);
+    MM(5,5) = 0.25 * (A[0][2][0][2] + A[2][0][2][0] + A[2][0][0][2] + A[0][2][2][0]);
+  }
+#undef MM
+}
+
+/* MiehePhaseMaterial::getposProj_, src/materials/MiehePhaseMaterial.cpp:342-406 */
+static void miehe_pos_proj(quad4_t P, const double T[3][3]) {
+  double val[3], V[3][3], epos[3], diag[3];
+  memset(P, 0, sizeof(quad4_t));
+  sym_eig3(T, val, V);
+  for (int i = 0; i < 3; i++) { epos[i] = macaulayP(val[i]); diag[i] = (val[i] > 0.0) ? 1.0 : 0.0; }
+  double M[3][3][3];                       /* M[a] = n_a (x) n_a ; V[:,a] is eigenvector a */
+  for (int a = 0; a < 3; a++)
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[a][i][j] = V[i][a] * V[j][a];
+  for (int r = 0; r < 3; r++)
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+      for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++)
+        P[i][j][k][l] += M[r][i][j] * M[r][k][l] * diag[r];
+  for (int a = 0; a < 3; a++) for (int b = 0; b < a; b++) {
+    double theta;
+    if (fabs(val[a] - val[b]) <= 1e-13) theta = 0.5 * (diag[a] + diag[b]) / 2.0;
+    else                                theta = 0.5 * (epos[a] - epos[b]) / (val[a] - val[b]);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+      for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) {
+        /* otimesu(A,B)_ijkl = A_ik B_jl ; otimesl(A,B)_ijkl = A_il B_jk  (TensorUtils.cpp:108-171) */
+        double Gab = M[a][i][k] * M[b][j][l] + M[a][i][l] * M[b][j][k];
+        double Gba = M[b][i][k] * M[a][j][l] + M[b][i][l] * M[a][j][k];
+        P[i][j][k][l] += theta * (Gab + Gba);
+      }
+  }
+}
+
+/* MiehePhaseMaterial::update, src/materials/MiehePhaseMaterial.cpp:200-258 (+ configure :97-99) */
+static void miehe_update(int rank, double E, double nu, const double* c, double gphi,
+                         double* stress, double* stiff, double* psi, double* stressP) {
+  const int n = STRAIN_COUNTS[rank];
+  const double K = E / (3.0 * (1.0 - 2.0 * nu));
+  const double G = E / (2.0 * (1.0 + nu));
+  const double lmda = K - 0.666666667 * G;       /* literal, MiehePhaseMaterial.cpp:99 */
+  double T[3][3] = { {0} };                      /* voigt2tensorStrain, TensorUtils.cpp:467-492 */
+  T[0][0] = c[0]; T[1][1] = c[1]; T[2][2] = c[2];
+  T[0][1] = T[1][0] = .5 * c[3];
+  if (n == 6) { T[1][2] = T[2][1] = .5 * c[4]; T[2][0] = T[0][2] = .5 * c[5]; }
+
+  static __thread quad4_t posP, negP, jac;
+  miehe_pos_proj(posP, T);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+    for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) {
+      double I4 = 0.5 * ((i == k) && (j == l)) + 0.5 * ((i == l) && (j == k));
+      negP[i][j][k][l] = I4 - posP[i][j][k][l];
+    }
+  double sp[3][3], sn[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double s = 0.0;
+    for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) s += posP[i][j][k][l] * T[k][l];
+    sp[i][j] = s; sn[i][j] = T[i][j] - s;
+  }
+  double tr = T[0][0] + T[1][1] + T[2][2];
+  double sigP[3][3], sigN[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double I2 = (i == j) ? 1.0 : 0.0;
+    sigP[i][j] = lmda * macaulayP(tr) * I2 + 2.0 * G * sp[i][j];
+    sigN[i][j] = lmda * macaulayN(tr) * I2 + 2.0 * G * sn[i][j];
+  }
+  /* tensor2voigtStress, TensorUtils.cpp:436-460 */
+  double vP[MAXSTR], vN[MAXSTR];
+  vP[0] = sigP[0][0]; vP[1] = sigP[1][1]; vP[2] = sigP[2][2]; vP[3] = 0.5 * (sigP[0][1] + sigP[1][0]);
+  vN[0] = sigN[0][0]; vN[1] = sigN[1][1]; vN[2] = sigN[2][2]; vN[3] = 0.5 * (sigN[0][1] + sigN[1][0]);
+  if (n == 6) {
+    vP[4] = 0.5 * (sigP[1][2] + sigP[2][1]); vP[5] = 0.5 * (sigP[0][2] + sigP[2][0]);
+    vN[4] = 0.5 * (sigN[1][2] + sigN[2][1]); vN[5] = 0.5 * (sigN[0][2] + sigN[2][0]);
+  }
+  for (int i = 0; i < n; i++) { stress[i] = gphi * vP[i] + vN[i]; stressP[i] = vP[i]; }
+  double dd = 0.0;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) dd += sp[i][j] * sp[i][j];
+  *psi = 0.5 * lmda * pow(macaulayP(tr), 2.0) + G * dd;
+  double signpos = heavisideP(tr), signneg = 1.0 - signpos;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+    for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) {
+      double II = ((i == j) && (k == l)) ? 1.0 : 0.0;
+      jac[i][j][k][l] = gphi * (2.0 * G * posP[i][j][k][l] + lmda * signpos * II)
+                             + (2.0 * G * negP[i][j][k][l] + lmda * signneg * II);
+    }
+  tensor2voigt(jac, n, stiff);
+}
+
+int fo_material_update(const fo_config* cfg, int rank, const double* strain, double gphi,
+                       double* stress, double* stiff, double* psi, double* stressP) {
+  const int n = STRAIN_COUNTS[rank];
+  switch (cfg->material) {
+    case FO_HOOKE:   /* HookeMaterial::update, HookeMaterial.cpp:152-166 */
+      if (hooke_stiff(rank, cfg->state, cfg->young, cfg->poisson, stiff)) return -1;
+      matvec(n, stiff, strain, stress);
+      if (psi) *psi = 0.0;
+      return 0;
+    case FO_AMOR:
+      amor_update(rank, cfg->young, cfg->poisson, strain, gphi, stress, stiff, psi, stressP);
+      return 0;
+    case FO_BOURDIN:
+      return bourdin_update(rank, cfg->state, cfg->young, cfg->poisson, strain, gphi, stress, stiff, psi, stressP);
+    case FO_MIEHE:
+      miehe_update(rank, cfg->young, cfg->poisson, strain, gphi, stress, stiff, psi, stressP);
+      return 0;
+  }
+  FAIL("unknown material %d", cfg->material);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Fracture constants: PhaseFractureModel.cpp:296-355                        */
+/* ------------------------------------------------------------------------- */
+typedef struct { double cw, eta, p, a1, a2, a3, psi0; } frac_t;
+
+static int frac_init(const fo_config* cfg, frac_t* f) {
+  const double E = cfg->young, gc = cfg->gc, l0 = cfg->l0, sT = cfg->sigma_t;
+  switch (cfg->frac_type) {
+    case FO_AT1: f->cw = 8.0 / 3.0; f->eta = 1.0; f->p = 2.0; f->a1 = 2.0; f->a2 = -0.5; f->a3 = 0.0;
+                 f->psi0 = (3. * gc) / (16. * l0); return 0;
+    case FO_AT2: f->cw = 2.0; f->eta = 0.0; f->p = 2.0; f->a1 = 2.0; f->a2 = -0.5; f->a3 = 0.0;
+                 f->psi0 = 0.0; return 0;
+    case FO_CZM_LINEAR: f->cw = 3.14159265359; f->eta = 2.0; f->p = 2.0;
+                 f->a1 = (4.0 * E * gc) / (f->cw * l0 * sT * sT); f->a2 = -0.5; f->a3 = 0.0;
+                 f->psi0 = 0.5 * (sT * sT) / E; return 0;
+    case FO_CZM_EXPONENTIAL: f->cw = 3.14159265359; f->eta = 2.0; f->p = 2.5;
+                 f->a1 = (4.0 * E * gc) / (f->cw * l0 * sT * sT); f->a2 = pow(2.0, 5.0 / 3.0) - 3.0; f->a3 = 0.0;
+                 f->psi0 = 0.5 * (sT * sT) / E; return 0;
+    case FO_CZM_CORNELISSEN: f->cw = 3.14159265359; f->eta = 2.0; f->p = 2.0;
+                 f->a1 = (4.0 * E * gc) / (f->cw * l0 * sT * sT); f->a2 = 1.3868; f->a3 = 0.6567;
+                 f->psi0 = 0.5 * (sT * sT) / E; return 0;
+    case FO_CZM_HYPERBOLIC: f->cw = 3.14159265359; f->eta = 2.0; f->p = 4.0;
+                 f->a1 = (4.0 * E * gc) / (f->cw * l0 * sT * sT); f->a2 = pow(2.0, 7.0 / 3.0) - 4.5; f->a3 = 0.0;
+                 f->psi0 = 0.5 * (sT * sT) / E; return 0;
+  }
+  FAIL("unexpected definition of fracture type %d", cfg->frac_type);
+}
+
+double fo_psi0(const fo_config* cfg) { frac_t f; if (frac_init(cfg, &f)) return NAN; return f.psi0; }
+
+/* PhaseFractureModel.cpp:660-676 */
+static void degradation(const frac_t* f, double pf, double* g, double* dg, double* ddg) {
+  const double p_ = f->p, a1_ = f->a1, a2_ = f->a2, a3_ = f->a3;
+  double gphi_n   = pow(1 - pf, p_);
+  double gphi_d   = gphi_n + a1_ * pf + a1_ * a2_ * pf * pf + a1_ * a2_ * a3_ * pf * pf * pf;
+  *g              = gphi_n / gphi_d + 1.e-7;
+  double dgphi_n  = -p_ * (pow(1 - pf, p_ - 1));
+  double dgphi_d  = dgphi_n + a1_ + 2.0 * a1_ * a2_ * pf + 3.0 * a1_ * a2_ * a3_ * pf * pf;
+  double ddgphi_n = p_ * (p_ - 1) * (pow(1 - pf, p_ - 2));
+  double ddgphi_d = ddgphi_n + 2.0 * a1_ * a2_ + 6.0 * a1_ * a2_ * a3_ * pf;
+  *dg  = (dgphi_n * gphi_d - gphi_n * dgphi_d) / (gphi_d * gphi_d);
+  *ddg = ((ddgphi_n * gphi_d - gphi_n * ddgphi_d) * gphi_d - 2.0 *
+          (dgphi_n * gphi_d - gphi_n * dgphi_d) * dgphi_d)
+         / (gphi_d * gphi_d * gphi_d);
+}
+
+void fo_degradation(const fo_config* cfg, double pf, double* g, double* dg, double* ddg) {
+  frac_t f;
+  if (frac_init(cfg, &f)) { *g = *dg = *ddg = NAN; return; }
+  degradation(&f, pf, g, dg, ddg);
+}
+
+int fo_ndof_per_node(int model, int rank) { return (model == FO_LINEAR_ELASTICITY) ? rank : rank + 1; }
+
+/* ------------------------------------------------------------------------- */
+/* Canonical DOF numbering + CSR pattern (Jive XDofSpace / FEM MatrixBuilder  */
+/* stand-in): dof = node*ndofpn + type; row columns sorted ascending.         */
+/* type_pair_mask bit (i*ndofpn + j) set => entry (type i row, type j col).   */
+/* ------------------------------------------------------------------------- */
+int64_t fo_pattern(int nnode, int64_t nel, int npe, const int32_t* conn, int ndofpn, int rank,
+                   int kind, int keep_off_diags, int64_t* row_ptr, int32_t* col_idx) {
+  (void)rank;
+  /* kind/keep_off_diags -> mask; kind FULL = all pairs; WRITTEN = (u,u),(phi,phi)[,(u,phi),(phi,u)];
+   * keep_off_diags: 0 none, 1 both (PhaseFracture), 2 phi-u only (PhaseFractureExt*) */
+  unsigned mask = 0;
+  for (int i = 0; i < ndofpn; i++) for (int j = 0; j < ndofpn; j++) {
+    int on = 1;
+    if (kind == FO_PATTERN_WRITTEN && ndofpn == rank + 1) {
+      int iu = i < rank, ju = j < rank;
+      if (iu != ju) on = (keep_off_diags == 1) || (keep_off_diags == 2 && !iu && ju);
+    }
+    if (on) mask |= 1u << (i * ndofpn + j);
+  }
+  int cnt_type[4] = { 0, 0, 0, 0 };       /* entries per neighbour node for a row of type i */
+  for (int i = 0; i < ndofpn; i++) for (int j = 0; j < ndofpn; j++)
+    if (mask >> (i * ndofpn + j) & 1) cnt_type[i]++;
+
+  int64_t* nptr = (int64_t*)calloc((size_t)nnode + 1, sizeof(int64_t));
+  if (!nptr) FAIL("out of memory");
+  for (int64_t e = 0; e < nel; e++) for (int a = 0; a < npe; a++) nptr[conn[e * npe + a] + 1]++;
+  for (int n = 0; n < nnode; n++) nptr[n + 1] += nptr[n];
+  int64_t* nelm = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nptr[nnode] ? nptr[nnode] : 1));
+  int64_t* fill = (int64_t*)malloc(sizeof(int64_t) * ((size_t)nnode + 1));
+  if (!nelm || !fill) FAIL("out of memory");
+  memcpy(fill, nptr, sizeof(int64_t) * ((size_t)nnode + 1));
+  for (int64_t e = 0; e < nel; e++) for (int a = 0; a < npe; a++) nelm[fill[conn[e * npe + a]]++] = e;
+  free(fill);
+
+  int32_t nb[1024];
+  int64_t pos = 0;
+  row_ptr[0] = 0;
+  for (int n = 0; n < nnode; n++) {
+    int m = 0;
+    for (int64_t k = nptr[n]; k < nptr[n + 1]; k++) {
+      const int32_t* c = conn + nelm[k] * npe;
+      for (int a = 0; a < npe; a++) {
+        int32_t v = c[a]; int j = m;
+        while (j > 0 && nb[j - 1] > v) j--;
+        if (j > 0 && nb[j - 1] == v) continue;
+        if (m >= 1024) FAIL("node valence too large");
+        memmove(nb + j + 1, nb + j, sizeof(int32_t) * (size_t)(m - j));
+        nb[j] = v; m++;
+      }
+    }
+    for (int i = 0; i < ndofpn; i++) {
+      if (col_idx)
+        for (int k = 0; k < m; k++)
+          for (int j = 0; j < ndofpn; j++)
+            if (mask >> (i * ndofpn + j) & 1) col_idx[pos++] = nb[k] * ndofpn + j;
+      if (!col_idx) pos += (int64_t)m * cnt_type[i];
+      row_ptr[(int64_t)n * ndofpn + i + 1] = pos;
+    }
+  }
+  free(nptr); free(nelm);
+  return pos;
+}
+
+/* MatrixBuilder::addBlock stand-in: K(irows, jcols) += block; per-entry binary search */
+static int add_block(const int64_t* row_ptr, const int32_t* col_idx, double* val,
+                     int nr, const int64_t* irows, int nc, const int64_t* jcols,
+                     const double* block /* nr x nc row-major */) {
+  for (int i = 0; i < nr; i++) {
+    int64_t lo0 = row_ptr[irows[i]], hi0 = row_ptr[irows[i] + 1];
+    for (int j = 0; j < nc; j++) {
+      int64_t lo = lo0, hi = hi0; int32_t c = (int32_t)jcols[j];
+      while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (col_idx[mid] < c) lo = mid + 1; else hi = mid; }
+      if (lo >= hi0 || col_idx[lo] != c) FAIL("addBlock: entry (%lld,%lld) not in pattern",
+                                               (long long)irows[i], (long long)jcols[j]);
+      val[lo] += block[i * nc + j];
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* The hot loop                                                              */
+/* ------------------------------------------------------------------------- */
+int fo_assemble(const fo_config* cfg,
+                int nnode, const double* coords,
+                int64_t nel, const int32_t* conn,
+                int64_t el_begin, int64_t el_end,
+                const int64_t* row_ptr, const int32_t* col_idx,
+                const double* state, const double* state0, const double* state00,
+                double dt_, double dt0_,
+                const double* hist_pre, double* hist_new,
+                double* strain_cache,
+                double* Kval, double* force, double* err_ext) {
+  (void)nnode; (void)nel;
+  shape_t sh;
+  if (shape_init(&sh, cfg->shape)) return -1;
+  const int rank = sh.rank, nodeCount = sh.npe, ipCount = sh.nip;
+  const int strCount = STRAIN_COUNTS[rank];
+  const int dispCount = nodeCount * rank, phiCount = nodeCount;
+  const int model = cfg->model;
+  const int isPF = (model != FO_LINEAR_ELASTICITY);
+  const int ndofpn = fo_ndof_per_node(model, rank);
+  const int srows = isPF ? strCount + 1 : strCount;
+  const int mbuilder = (Kval != NULL);
+
+  frac_t fr; memset(&fr, 0, sizeof fr);
+  if (isPF && frac_init(cfg, &fr)) return -1;
+  if (isPF && cfg->material == FO_HOOKE) FAIL("phase-field model needs a PhaseFractureMaterial");
+  if (!isPF && cfg->material != FO_HOOKE) FAIL("LinearElasticity is restated with Hooke only");
+  const double gc_ = cfg->gc, l0_ = cfg->l0, cw_ = fr.cw, eta_ = fr.eta, beta_ = cfg->beta, Psi0_ = fr.psi0;
+
+  static __thread double grads[MAXNIP][MAXNPE][3];
+  double xc[MAXNPE][3], ipWeights[MAXNIP];
+  double disp[MAXND], phi[MAXNPE], phi0[MAXNPE], phiX[MAXNPE];
+  double stiff[MAXSTR * MAXSTR], stress[MAXSTR], strain[MAXSTR], stressP[MAXSTR];
+  double elemForce1[MAXND], elemForce2[MAXNPE];
+  static __thread double elemMat1[MAXND * MAXND], elemMat2[MAXND * MAXNPE], elemMat3[MAXNPE * MAXND],
+                         elemMat4[MAXNPE * MAXNPE];
+  static __thread double bd[MAXSTR * MAXND], DB[MAXSTR * MAXND];
+  double sPB[MAXND], BeBe[MAXNPE * MAXNPE];
+  int64_t dispDofs[MAXND], phiDofs[MAXNPE];
+  double errExt = 0.0;
+
+  for (int64_t ie = el_begin; ie < el_end; ie++) {
+    const int32_t* inodes = conn + ie * nodeCount;
+    for (int a = 0; a < nodeCount; a++) {
+      for (int i = 0; i < 3; i++) xc[a][i] = (i < rank) ? coords[(int64_t)inodes[a] * rank + i] : 0.0;
+      /* XDofSpace::getDofIndices: node-major, type-minor */
+      for (int i = 0; i < rank; i++) dispDofs[a * rank + i] = (int64_t)inodes[a] * ndofpn + i;
+      phiDofs[a] = (int64_t)inodes[a] * ndofpn + rank;
+    }
+    if (shape_gradients(&sh, (const double (*)[3])xc, grads, ipWeights)) return -1;
+
+    for (int i = 0; i < dispCount; i++) disp[i] = state[dispDofs[i]];
+    if (isPF) for (int a = 0; a < phiCount; a++) phi[a] = state[phiDofs[a]];
+    if (model >= FO_PHASE_FRACTURE_EXT)
+      for (int a = 0; a < phiCount; a++) { phi0[a] = state0[phiDofs[a]]; phiX[a] = state00[phiDofs[a]]; }
+
+    memset(elemForce1, 0, sizeof elemForce1); memset(elemForce2, 0, sizeof elemForce2);
+    if (mbuilder) {
+      memset(elemMat1, 0, sizeof(double) * dispCount * dispCount);
+      memset(elemMat2, 0, sizeof(double) * dispCount * phiCount);
+      memset(elemMat3, 0, sizeof(double) * phiCount * dispCount);
+      memset(elemMat4, 0, sizeof(double) * phiCount * phiCount);
+    }
+
+    for (int ip = 0; ip < ipCount; ip++) {
+      const int64_t ipoint = ie * ipCount + ip;          /* initializeIPMPMap_, PhaseFractureModel.cpp:1070-1093 */
+      fill_B(rank, nodeCount, (const double (*)[3])grads[ip], bd);
+      for (int c = 0; c < strCount; c++) {               /* matmul(strain, bd, disp) */
+        double s = 0.0;
+        for (int j = 0; j < dispCount; j++) s += bd[c * dispCount + j] * disp[j];
+        strain[c] = s;
+      }
+      if (strain_cache) for (int c = 0; c < strCount; c++) strain_cache[ipoint * srows + c] = strain[c];
+      const double wip = ipWeights[ip];
+
+      if (!isPF) {
+        /* LinearElasticityModel.cpp:411-420 */
+        if (fo_material_update(cfg, rank, strain, 0.0, stress, stiff, NULL, NULL)) return -1;
+      } else {
+        const double* Nip = sh.N[ip];
+        double pf = dotn(phiCount, Nip, phi);
+        double gphi, dgphi, ddgphi, gmat;
+        double pf0 = 0.0;
+        if (model == FO_PHASE_FRACTURE) {
+          degradation(&fr, pf, &gphi, &dgphi, &ddgphi);
+          gmat = gphi;
+        } else {
+          /* PhaseFractureExtModel.cpp:656-711 / PhaseFractureExtItModel.cpp (diff: pfEx source, errExt_) */
+          pf0 = dotn(phiCount, Nip, phi0);
+          double pfEx;
+          if (model == FO_PHASE_FRACTURE_EXT) {
+            double pf00 = dotn(phiCount, Nip, phiX);
+            if (dt0_ < 1.e-15) pfEx = pf0;
+            else               pfEx = -pf00 * dt_ / dt0_ + pf0 * (dt_ + dt0_) / dt0_;
+          } else {
+            pfEx = dotn(phiCount, Nip, phiX);
+            errExt += pow(pf - pfEx, 2.0);
+          }
+          if (pfEx < 0.0) pfEx = 0.0; else if (pfEx > 1.0) pfEx = 1.0;
+          double d1, d2;
+          degradation(&fr, pfEx, &gmat, &d1, &d2);       /* only g(pfEx)+1e-7 is used */
+          double gdummy;
+          degradation(&fr, pf, &gdummy, &dgphi, &ddgphi);
+        }
+        if (strain_cache) strain_cache[ipoint * srows + strCount] = gmat;
+        double dw  = eta_ + 2.0 * (1 - eta_) * pf;
+        double ddw = 2.0 * (1 - eta_);
+        double Psi;
+        if (fo_material_update(cfg, rank, strain, gmat, stress, stiff, &Psi, stressP)) return -1;
+        double loading = 1.0;
+        if (model == FO_PHASE_FRACTURE) {
+          const double H0 = hist_pre[ipoint];            /* PhaseFractureModel.cpp:696-703 */
+          if (Psi < H0) loading = 0.0;
+          Psi = (Psi > H0) ? Psi : H0;
+          hist_new[ipoint] = Psi;
+        } else {
+          Psi = (Psi > Psi0_) ? Psi : Psi0_;             /* PhaseFractureExtModel.cpp:726 */
+        }
+        /* be^T be  (mc2.matmul(bet, be)) */
+        for (int a = 0; a < phiCount; a++) for (int b = 0; b < phiCount; b++) {
+          double s = 0.0;
+          for (int i = 0; i < rank; i++) s += grads[ip][a][i] * grads[ip][b][i];
+          BeBe[a * phiCount + b] = s;
+        }
+        if (mbuilder) {
+          const double c1 = gc_ / (cw_ * l0_) * ddw + ddgphi * Psi, c2 = 2.0 * gc_ * l0_ / cw_;
+          for (int a = 0; a < phiCount; a++) for (int b = 0; b < phiCount; b++)
+            elemMat4[a * phiCount + b] += wip * (c1 * (Nip[a] * Nip[b]) + c2 * BeBe[a * phiCount + b]);
+          const int k2 = (model == FO_PHASE_FRACTURE) && cfg->keep_off_diags;
+          const int k3 = (model == FO_PHASE_FRACTURE) ? cfg->keep_off_diags : 1;
+          if (k2 || k3) {
+            for (int j = 0; j < dispCount; j++) {          /* matmul(stressP, bd) */
+              double s = 0.0;
+              for (int c = 0; c < strCount; c++) s += stressP[c] * bd[c * dispCount + j];
+              sPB[j] = s;
+            }
+            if (k2) for (int i = 0; i < dispCount; i++) for (int b = 0; b < phiCount; b++) {
+              /* bdt * (stressP (x) Nip)  == (bdt*stressP) (x) Nip */
+              double s = 0.0;
+              for (int c = 0; c < strCount; c++) s += bd[c * dispCount + i] * (stressP[c] * Nip[b]);
+              elemMat2[i * phiCount + b] += wip * dgphi * s;
+            }
+            if (k3) for (int a = 0; a < phiCount; a++) for (int j = 0; j < dispCount; j++)
+              elemMat3[a * dispCount + j] += wip * loading * dgphi * (Nip[a] * sPB[j]);
+          }
+        }
+        {
+          const double cf = gc_ / (cw_ * l0_) * dw + dgphi * Psi, c2 = 2.0 * gc_ * l0_ / cw_;
+          for (int a = 0; a < phiCount; a++) {
+            double s = 0.0;
+            for (int b = 0; b < phiCount; b++) s += BeBe[a * phiCount + b] * phi[b];
+            elemForce2[a] += wip * (Nip[a] * cf + c2 * s);
+          }
+        }
+        if (model >= FO_PHASE_FRACTURE_EXT && (pf0 - pf > 1.e-15)) {   /* PhaseFractureExtModel.cpp:752-758 */
+          const double cp = gc_ / (cw_ * l0_) * beta_;
+          if (mbuilder) for (int a = 0; a < phiCount; a++) for (int b = 0; b < phiCount; b++)
+            elemMat4[a * phiCount + b] += wip * (cp * (Nip[a] * Nip[b]));
+          for (int a = 0; a < phiCount; a++) elemForce2[a] -= wip * (cp * (pf0 - pf)) * Nip[a];
+        }
+      }
+
+      if (mbuilder) {
+        /* elemMat1 += wip * bdt * stiff * bd   (dense 3-chain) */
+        for (int c = 0; c < strCount; c++) for (int j = 0; j < dispCount; j++) {
+          double s = 0.0;
+          for (int k = 0; k < strCount; k++) s += stiff[c * strCount + k] * bd[k * dispCount + j];
+          DB[c * dispCount + j] = s;
+        }
+        for (int i = 0; i < dispCount; i++) for (int j = 0; j < dispCount; j++) {
+          double s = 0.0;
+          for (int c = 0; c < strCount; c++) s += bd[c * dispCount + i] * DB[c * dispCount + j];
+          elemMat1[i * dispCount + j] += wip * s;
+        }
+      }
+      for (int i = 0; i < dispCount; i++) {              /* elemForce1 += wip * bdt * stress */
+        double s = 0.0;
+        for (int c = 0; c < strCount; c++) s += bd[c * dispCount + i] * stress[c];
+        elemForce1[i] += wip * s;
+      }
+    }
+
+    if (mbuilder) {
+      if (add_block(row_ptr, col_idx, Kval, dispCount, dispDofs, dispCount, dispDofs, elemMat1)) return -1;
+      if (isPF) {
+        const int k2 = (model == FO_PHASE_FRACTURE) && cfg->keep_off_diags;
+        const int k3 = (model == FO_PHASE_FRACTURE) ? cfg->keep_off_diags : 1;
+        if (add_block(row_ptr, col_idx, Kval, phiCount, phiDofs, phiCount, phiDofs, elemMat4)) return -1;
+        if (k2 && add_block(row_ptr, col_idx, Kval, dispCount, dispDofs, phiCount, phiDofs, elemMat2)) return -1;
+        if (k3 && add_block(row_ptr, col_idx, Kval, phiCount, phiDofs, dispCount, dispDofs, elemMat3)) return -1;
+      }
+    }
+    for (int i = 0; i < dispCount; i++) force[dispDofs[i]] += elemForce1[i];
+    if (isPF) for (int a = 0; a < phiCount; a++) force[phiDofs[a]] += elemForce2[a];
+  }
+  if (err_ext) *err_ext = errExt;
+  return 0;
+}

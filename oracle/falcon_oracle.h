@@ -1,0 +1,126 @@
+/*
+ * falcon_oracle.h -- CPU restatement of falcon's element-level K / f_int assembly.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the checker, never the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * PARITY UNPINNED: the reference (ritukeshbharali/falcon) cannot be built here
+ * (needs the external Jem/Jive 3.0 libraries) and ships no golden numeric
+ * vectors (its tests are smoke tests, tests/do_tests.sh:47-59).  This oracle is
+ * a restatement of the reference's arithmetic, file:line cited per function,
+ * pinned only by analytic known-answer tests (tests/test_oracle_kat.py).
+ * Jive-internal pieces (shape functions, Gauss rules, DOF numbering, CSR
+ * pattern, matmul summation order, EigenUtils::symSolve) are restated from
+ * their published/standard definitions and are not pinned by any reference
+ * fixture.
+ */
+#ifndef FALCON_ORACLE_H
+#define FALCON_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* shape + integration scheme ids (Jive shape.type / shape.intScheme strings) */
+enum {
+  FO_TRI3_G1   = 0, /* Triangle3, Gauss1                    */
+  FO_TRI3_G3   = 1, /* Triangle3, Gauss3                    */
+  FO_QUAD4_G2  = 2, /* Quad4,     Gauss2*Gauss2             */
+  FO_QUAD8_G3  = 3, /* Quad8,     Gauss3*Gauss3             */
+  FO_QUAD8_G2  = 4, /* Quad8,     Gauss2*Gauss2             */
+  FO_TRI6_G3   = 5, /* Triangle6, Gauss3                    */
+  FO_HEX8_G2   = 6, /* Hex8,      Gauss2*Gauss2*Gauss2      */
+  FO_HEX20_G3  = 7, /* Hex20,     Gauss3*Gauss3*Gauss3      */
+  FO_HEX20_G2  = 8, /* Hex20,     Gauss2*Gauss2*Gauss2      */
+  FO_SHAPE_COUNT = 9
+};
+
+/* model ids: ModelFactory names in src/fem/solidmech/FalconSolidMechModels.cpp:10-22 */
+enum {
+  FO_LINEAR_ELASTICITY   = 0,
+  FO_PHASE_FRACTURE      = 1,
+  FO_PHASE_FRACTURE_EXT  = 2,
+  FO_PHASE_FRACTURE_EXTIT= 3
+};
+
+/* material ids: newMaterial, src/materials/Material.cpp:233-244 */
+enum { FO_HOOKE = 0, FO_AMOR = 1, FO_BOURDIN = 2, FO_MIEHE = 3 };
+
+/* 2D problem state (HookeMaterial.cpp:92-103) */
+enum { FO_PLANE_STRAIN = 0, FO_PLANE_STRESS = 1 };
+
+/* fracture types (PhaseFractureModel.cpp:67-72) */
+enum { FO_AT1 = 0, FO_AT2 = 1, FO_CZM_LINEAR = 2, FO_CZM_EXPONENTIAL = 3,
+       FO_CZM_CORNELISSEN = 4, FO_CZM_HYPERBOLIC = 5 };
+
+/* canonical pattern kinds */
+enum { FO_PATTERN_FULL = 0,   /* every dof-type pair of every node pair sharing an element */
+       FO_PATTERN_WRITTEN = 1 /* only the blocks the model writes (u-u, phi-phi[, u-phi, phi-u]) */ };
+
+typedef struct {
+  int    shape;          /* FO_* shape id            */
+  int    model;          /* FO_* model id            */
+  int    material;       /* FO_* material id         */
+  int    state;          /* FO_PLANE_*  (rank 2)     */
+  double young, poisson;
+  int    frac_type;      /* FO_AT1...                */
+  double gc, l0, sigma_t, beta;
+  int    keep_off_diags; /* PhaseFracture only       */
+} fo_config;
+
+typedef struct {
+  int rank, npe, nip, str;
+} fo_shape_info;
+
+int  fo_shape_info_get(int shape, fo_shape_info* out);
+/* N[nip*npe] (ip-major), dN[nip*npe*rank], w[nip] on the reference element */
+int  fo_shape_tables(int shape, double* N, double* dN, double* w);
+
+/* dofs per node for a model */
+int  fo_ndof_per_node(int model, int rank);
+
+/* Psi0 = initial history value, PhaseFractureModel.cpp:296-359 */
+double fo_psi0(const fo_config* cfg);
+
+/* degradation function g, g', g'' at phi (PhaseFractureModel.cpp:660-676); g carries the +1e-7 */
+void fo_degradation(const fo_config* cfg, double pf, double* g, double* dg, double* ddg);
+
+/* single material-point update; strain[str] -> stress[str], stiff[str*str] (row-major), psi, stressP[str]
+ * gphi ignored for Hooke. */
+int  fo_material_update(const fo_config* cfg, int rank, const double* strain, double gphi,
+                        double* stress, double* stiff, double* psi, double* stressP);
+
+/* canonical CSR pattern: node-major dofs (dof = node*ndofpn + type), rows column-sorted.
+ * kind FO_PATTERN_FULL: every dof-type pair; FO_PATTERN_WRITTEN: (u,u),(phi,phi) plus,
+ * by keep_off_diags: 0 nothing, 1 (u,phi)+(phi,u) [PhaseFracture keepOffDiags], 2 (phi,u) only
+ * [PhaseFractureExt*].  Call with col_idx == NULL to get row_ptr only
+ * (row_ptr has nnode*ndofpn+1 entries).  Returns nnz. */
+int64_t fo_pattern(int nnode, int64_t nel, int npe, const int32_t* conn, int ndofpn, int rank,
+                   int kind, int keep_off_diags, int64_t* row_ptr, int32_t* col_idx);
+
+/* Element-serial assembly (LinearElasticityModel.cpp:297-430, PhaseFractureModel.cpp:502-751,
+ * PhaseFractureExtModel.cpp:488-774, PhaseFractureExtItModel.cpp:518-797).
+ * K_values may be NULL (GET_INT_VECTOR).  K and f are ACCUMULATED into.
+ * state0/state00: Ext;  state0/state_ext: ExtIt.  hist_pre/hist_new: PhaseFracture (nel*nip).
+ * strain_cache: (str[+1]) x (nel*nip), column = ipoint, may be NULL.
+ * err_ext: ExtIt output (sum (pf-pfEx)^2), may be NULL.
+ * el_begin/el_end: element range (for bounded timing samples and partition tests). */
+int  fo_assemble(const fo_config* cfg,
+                 int nnode, const double* coords,      /* nnode*rank, node-major */
+                 int64_t nel, const int32_t* conn,     /* nel*npe */
+                 int64_t el_begin, int64_t el_end,
+                 const int64_t* row_ptr, const int32_t* col_idx,
+                 const double* state, const double* state0, const double* state00,
+                 double dt, double dt0,
+                 const double* hist_pre, double* hist_new,
+                 double* strain_cache,
+                 double* K_values, double* f_int, double* err_ext);
+
+const char* fo_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

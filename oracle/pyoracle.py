@@ -1,0 +1,180 @@
+"""ctypes binding of the CPU oracle (oracle/falcon_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package.  PARITY UNPINNED
+(see falcon_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libfalcon_oracle.so")
+
+# shape ids
+TRI3_G1, TRI3_G3, QUAD4_G2, QUAD8_G3, QUAD8_G2, TRI6_G3, HEX8_G2, HEX20_G3, HEX20_G2 = range(9)
+# models
+LINEAR_ELASTICITY, PHASE_FRACTURE, PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT = range(4)
+# materials
+HOOKE, AMOR, BOURDIN, MIEHE = range(4)
+PLANE_STRAIN, PLANE_STRESS = 0, 1
+AT1, AT2, CZM_LINEAR, CZM_EXPONENTIAL, CZM_CORNELISSEN, CZM_HYPERBOLIC = range(6)
+PATTERN_FULL, PATTERN_WRITTEN = 0, 1
+
+
+class Config(C.Structure):
+    _fields_ = [("shape", C.c_int), ("model", C.c_int), ("material", C.c_int), ("state", C.c_int),
+                ("young", C.c_double), ("poisson", C.c_double),
+                ("frac_type", C.c_int),
+                ("gc", C.c_double), ("l0", C.c_double), ("sigma_t", C.c_double), ("beta", C.c_double),
+                ("keep_off_diags", C.c_int)]
+
+
+class ShapeInfo(C.Structure):
+    _fields_ = [("rank", C.c_int), ("npe", C.c_int), ("nip", C.c_int), ("str", C.c_int)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        dp, ip32, ip64 = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        L.fo_shape_info_get.argtypes = [C.c_int, C.POINTER(ShapeInfo)]
+        L.fo_shape_tables.argtypes = [C.c_int, dp, dp, dp]
+        L.fo_ndof_per_node.argtypes = [C.c_int, C.c_int]
+        L.fo_psi0.argtypes = [C.POINTER(Config)]
+        L.fo_psi0.restype = C.c_double
+        L.fo_degradation.argtypes = [C.POINTER(Config), C.c_double, dp, dp, dp]
+        L.fo_degradation.restype = None
+        L.fo_material_update.argtypes = [C.POINTER(Config), C.c_int, dp, C.c_double, dp, dp, dp, dp]
+        L.fo_pattern.argtypes = [C.c_int, C.c_int64, C.c_int, ip32, C.c_int, C.c_int, C.c_int, C.c_int, ip64, ip32]
+        L.fo_pattern.restype = C.c_int64
+        L.fo_assemble.argtypes = [C.POINTER(Config), C.c_int, dp, C.c_int64, ip32, C.c_int64, C.c_int64,
+                                  ip64, ip32, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp]
+        L.fo_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def shape_info(shape):
+    si = ShapeInfo()
+    if lib().fo_shape_info_get(shape, C.byref(si)):
+        raise ValueError(lib().fo_last_error().decode())
+    return si.rank, si.npe, si.nip, si.str
+
+
+def shape_tables(shape):
+    rank, npe, nip, _ = shape_info(shape)
+    N = np.zeros((nip, npe)); dN = np.zeros((nip, npe, rank)); w = np.zeros(nip)
+    lib().fo_shape_tables(shape, _p(N, C.c_double), _p(dN, C.c_double), _p(w, C.c_double))
+    return N, dN, w
+
+
+def ndof_per_node(model, rank):
+    return lib().fo_ndof_per_node(model, rank)
+
+
+def make_config(shape, model, material, state=PLANE_STRAIN, young=210e3, poisson=0.3, frac_type=AT2,
+                gc=2.7, l0=0.015, sigma_t=0.0, beta=6500.0, keep_off_diags=0):
+    return Config(shape, model, material, state, young, poisson, frac_type, gc, l0, sigma_t, beta,
+                  int(keep_off_diags))
+
+
+def psi0(cfg):
+    return lib().fo_psi0(C.byref(cfg))
+
+
+def degradation(cfg, pf):
+    g, dg, ddg = C.c_double(), C.c_double(), C.c_double()
+    lib().fo_degradation(C.byref(cfg), pf, C.byref(g), C.byref(dg), C.byref(ddg))
+    return g.value, dg.value, ddg.value
+
+
+def material_update(cfg, rank, strain, gphi=1.0):
+    n = {2: 4, 3: 6}[rank]
+    strain = np.ascontiguousarray(strain, dtype=np.float64)
+    stress = np.zeros(n); stiff = np.zeros((n, n)); sp = np.zeros(n); psi = C.c_double()
+    if lib().fo_material_update(C.byref(cfg), rank, _p(strain, C.c_double), gphi, _p(stress, C.c_double),
+                                _p(stiff, C.c_double), C.byref(psi), _p(sp, C.c_double)):
+        raise ValueError(lib().fo_last_error().decode())
+    return stress, stiff, psi.value, sp
+
+
+def keep_code(cfg):
+    """keep_off_diags code of fo_pattern for the WRITTEN pattern of this model."""
+    if cfg.model == PHASE_FRACTURE:
+        return 1 if cfg.keep_off_diags else 0
+    if cfg.model in (PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT):
+        return 2
+    return 0
+
+
+def pattern(nnode, conn, ndofpn, rank, kind=PATTERN_FULL, keep=0):
+    conn = np.ascontiguousarray(conn, dtype=np.int32)
+    nel, npe = conn.shape
+    row_ptr = np.zeros(nnode * ndofpn + 1, dtype=np.int64)
+    nnz = lib().fo_pattern(nnode, nel, npe, _p(conn, C.c_int32), ndofpn, rank, kind, keep,
+                           _p(row_ptr, C.c_int64), None)
+    if nnz < 0:
+        raise ValueError(lib().fo_last_error().decode())
+    col_idx = np.zeros(nnz, dtype=np.int32)
+    lib().fo_pattern(nnode, nel, npe, _p(conn, C.c_int32), ndofpn, rank, kind, keep,
+                     _p(row_ptr, C.c_int64), _p(col_idx, C.c_int32))
+    return row_ptr, col_idx
+
+
+def assemble(cfg, coords, conn, row_ptr, col_idx, state, state0=None, state00=None, dt=0.0, dt0=0.0,
+             hist_pre=None, want_K=True, want_strain=False, K=None, f=None, el_range=None):
+    """One GET_MATRIX0 (want_K) / GET_INT_VECTOR pass.  Returns dict(K, f, hist_new, strain, err_ext).
+    For ExtIt pass stateExt_ as state00."""
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    conn = np.ascontiguousarray(conn, dtype=np.int32)
+    nnode, rank = coords.shape
+    nel, npe = conn.shape
+    r, npe_s, nip, strc = shape_info(cfg.shape)
+    assert r == rank and npe_s == npe
+    ndof = nnode * ndof_per_node(cfg.model, rank)
+    state = np.ascontiguousarray(state, dtype=np.float64)
+    assert state.size == ndof
+    if K is None and want_K:
+        K = np.zeros(row_ptr[-1])
+    if f is None:
+        f = np.zeros(ndof)
+    hist_new = None
+    if cfg.model == PHASE_FRACTURE:
+        if hist_pre is None:
+            hist_pre = np.full(nel * nip, psi0(cfg))
+        hist_pre = np.ascontiguousarray(hist_pre, dtype=np.float64)
+        hist_new = np.zeros(nel * nip)
+    srows = strc + (0 if cfg.model == LINEAR_ELASTICITY else 1)
+    strain = np.zeros((nel * nip, srows)) if want_strain else None
+    err = C.c_double(0.0)
+    b, e = (0, nel) if el_range is None else el_range
+    if state0 is not None:
+        state0 = np.ascontiguousarray(state0, dtype=np.float64)
+    if state00 is not None:
+        state00 = np.ascontiguousarray(state00, dtype=np.float64)
+    rc = lib().fo_assemble(C.byref(cfg), nnode, _p(coords, C.c_double), nel, _p(conn, C.c_int32), b, e,
+                           _p(row_ptr, C.c_int64), _p(col_idx, C.c_int32),
+                           _p(state, C.c_double), _p(state0, C.c_double), _p(state00, C.c_double),
+                           dt, dt0, _p(hist_pre, C.c_double), _p(hist_new, C.c_double),
+                           _p(strain, C.c_double), _p(K if want_K else None, C.c_double), _p(f, C.c_double),
+                           C.byref(err))
+    if rc:
+        raise ValueError(lib().fo_last_error().decode())
+    return dict(K=K if want_K else None, f=f, hist_new=hist_new, strain=strain, err_ext=err.value)

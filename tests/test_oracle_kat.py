@@ -1,0 +1,301 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference ships no numeric goldens (tests/do_tests.sh only greps "Elapsed"), so these analytic
+checks -- closed forms derived from the reference's own formulas -- are what pins the oracle.
+"""
+import numpy as np
+import pytest
+
+from falcon_amd import meshgen
+from oracle import pyoracle as po
+from tests import np_ref
+
+ALL_SHAPES = [po.TRI3_G1, po.TRI3_G3, po.QUAD4_G2, po.QUAD8_G3, po.QUAD8_G2, po.TRI6_G3,
+              po.HEX8_G2, po.HEX20_G3, po.HEX20_G2]
+
+GRID = {po.TRI3_G1: lambda: meshgen.grid_tri3(3, 3), po.TRI3_G3: lambda: meshgen.grid_tri3(3, 3),
+        po.QUAD4_G2: lambda: meshgen.grid_quad4(3, 3), po.QUAD8_G3: lambda: meshgen.grid_quad8(3, 3),
+        po.QUAD8_G2: lambda: meshgen.grid_quad8(3, 3), po.TRI6_G3: lambda: meshgen.grid_tri6(3, 3),
+        po.HEX8_G2: lambda: meshgen.grid_hex8(2, 2, 2), po.HEX20_G3: lambda: meshgen.grid_hex20(2, 2, 2),
+        po.HEX20_G2: lambda: meshgen.grid_hex20(2, 2, 2)}
+
+
+def csr_dense(row_ptr, col_idx, val):
+    n = len(row_ptr) - 1
+    A = np.zeros((n, n))
+    for r in range(n):
+        A[r, col_idx[row_ptr[r]:row_ptr[r + 1]]] = val[row_ptr[r]:row_ptr[r + 1]]
+    return A
+
+
+def test_sm01_closed_form():
+    """KAT-1: tests/sm01 as shipped (2 Triangle3, Hooke plane stress, E=1e4, nu=0.3)."""
+    coords = np.array([[0., 0.], [1., 0.], [1., 1.], [0., 1.]])
+    conn = np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int32)
+    cfg = po.make_config(po.TRI3_G1, po.LINEAR_ELASTICITY, po.HOOKE, state=po.PLANE_STRESS, young=1e4, poisson=0.3)
+    rp, ci = po.pattern(4, conn, 2, 2)
+    assert rp[-1] == 56
+    u = np.zeros(8); u[5] = u[7] = 1e-4
+    out = po.assemble(cfg, coords, conn, rp, ci, u)
+    K = csr_dense(rp, ci, out["K"])
+    a = 1e4 / (1 - 0.09); G = a * 0.35
+    assert np.allclose(np.diag(K), (a + G) / 2, rtol=1e-14)
+    row0 = [(a + G) / 2, 0, -a / 2, a * 0.3 / 2, 0, -(a * 0.3 + G) / 2, -G / 2, G / 2]
+    assert np.allclose(K[0], row0, rtol=1e-13, atol=1e-10)
+    assert np.allclose(K[0], [7417.5824175824, 0, -5494.5054945055, 1648.3516483516, 0,
+                              -3571.4285714286, -1923.0769230769, 1923.0769230769], atol=1e-9)
+    assert np.allclose(K, K.T, atol=1e-10)
+    for (i, j) in [(2, 6), (2, 7), (3, 6), (3, 7)]:
+        assert j not in ci[rp[i]:rp[i + 1]] and i not in ci[rp[j]:rp[j + 1]]
+    f = out["f"]
+    assert np.allclose(f, [-0.1648351648, -0.5494505495, 0.1648351648, -0.5494505495,
+                           0.1648351648, 0.5494505495, -0.1648351648, 0.5494505495], atol=1e-10)
+    assert abs(f[5] + f[7] - 1.0989010989) < 1e-10          # Lodi load[1]
+
+
+@pytest.mark.parametrize("shape", ALL_SHAPES)
+def test_shape_tables(shape):
+    rank, npe, nip, _ = po.shape_info(shape)
+    N, dN, w = po.shape_tables(shape)
+    assert np.allclose(N.sum(1), 1.0, atol=1e-14)
+    assert np.allclose(dN.sum(1), 0.0, atol=1e-13)
+    vol = {2: 0.5 if npe in (3, 6) else 4.0, 3: 8.0}[rank]
+    assert abs(w.sum() - vol) < 1e-13
+
+
+@pytest.mark.parametrize("shape", ALL_SHAPES)
+def test_patch_and_rigid_body(shape):
+    """KAT-2/3: constant strain on a distorted mesh -> interior f_int = 0; K r = 0 for rigid modes; K sym."""
+    rank, npe, nip, strc = po.shape_info(shape)
+    coords, conn = GRID[shape]()
+    lo, hi = coords.min(0), coords.max(0)
+    interior = np.all((coords > lo + 1e-9) & (coords < hi - 1e-9), axis=1)
+    if npe in (3, 4) or shape == po.HEX8_G2:               # straight-sided distortion keeps the patch property
+        coords = meshgen.distort(coords, conn, 0.15)
+    nn = coords.shape[0]
+    cfg = po.make_config(shape, po.LINEAR_ELASTICITY, po.HOOKE, state=po.PLANE_STRAIN, young=3.0, poisson=0.25)
+    rp, ci = po.pattern(nn, conn, rank, rank)
+    A = np.array([[1e-3, 2e-3, -1e-3], [0.5e-3, -2e-3, 3e-3], [1e-3, 1e-3, 2e-3]])[:rank, :rank]
+    u = (coords @ A.T).ravel()
+    out = po.assemble(cfg, coords, conn, rp, ci, u, want_strain=True)
+    f = out["f"].reshape(nn, rank)
+    assert interior.any()
+    scale = np.abs(f).max()
+    assert np.abs(f[interior]).max() < 1e-12 * scale
+    eps = out["strain"]
+    assert np.allclose(eps[:, 0], A[0, 0], atol=1e-15) and np.allclose(eps[:, 3], A[0, 1] + A[1, 0], atol=1e-15)
+    K = csr_dense(rp, ci, out["K"])
+    assert np.allclose(K, K.T, atol=1e-12 * np.abs(K).max())
+    assert np.allclose(K @ u, out["f"], atol=1e-12 * scale)
+    modes = []
+    for i in range(rank):
+        r = np.zeros((nn, rank)); r[:, i] = 1; modes.append(r.ravel())
+    r = np.zeros((nn, rank)); r[:, 0] = -coords[:, 1]; r[:, 1] = coords[:, 0]; modes.append(r.ravel())
+    for r in modes:
+        assert np.abs(K @ r).max() < 1e-11 * np.abs(K).max()
+
+
+def test_degradation_at2_closed_form():
+    cfg = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE, po.AMOR, frac_type=po.AT2)
+    for pf in [0.0, 0.1, 0.5, 0.9, 1.0]:
+        g, dg, ddg = po.degradation(cfg, pf)
+        assert abs(g - ((1 - pf) ** 2 + 1e-7)) < 1e-15
+        assert abs(dg - (-2 * (1 - pf))) < 1e-14 and abs(ddg - 2.0) < 1e-13
+    assert po.psi0(cfg) == 0.0
+    cfg1 = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE, po.AMOR, frac_type=po.AT1, gc=2.7, l0=0.015)
+    assert po.psi0(cfg1) == 3 * 2.7 / (16 * 0.015)
+
+
+@pytest.mark.parametrize("ft", [po.CZM_LINEAR, po.CZM_EXPONENTIAL, po.CZM_CORNELISSEN, po.CZM_HYPERBOLIC])
+def test_degradation_czm_derivatives(ft):
+    cfg = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE, po.AMOR, frac_type=ft, young=3e4, gc=0.12, l0=2.5,
+                         sigma_t=3.0)
+    g0, dg0, _ = po.degradation(cfg, 0.0)
+    assert abs(g0 - 1.0 - 1e-7) < 1e-14
+    a1 = 4 * 3e4 * 0.12 / (3.14159265359 * 2.5 * 9.0)
+    assert abs(dg0 + a1) < 1e-10 * a1                       # g'(0) = -a1 for all CZM laws
+    h = 1e-6
+    for pf in [0.2, 0.6]:
+        g, dg, ddg = po.degradation(cfg, pf)
+        gp, dgp, _ = po.degradation(cfg, pf + h); gm, dgm, _ = po.degradation(cfg, pf - h)
+        assert abs((gp - gm) / (2 * h) - dg) < 1e-7 * max(1, abs(dg))
+        assert abs((dgp - dgm) / (2 * h) - ddg) < 1e-6 * max(1, abs(ddg))
+
+
+def test_amor_compression_undegraded():
+    """KAT-6: tr eps < 0 -> volumetric part carries no g."""
+    cfg = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE, po.AMOR, young=100.0, poisson=0.2)
+    K = 100 / (3 * 0.6); G = 100 / 2.4
+    eps = np.array([-1e-3, -2e-3, 0.0, 0.5e-3])
+    g = 0.3
+    sig, D, psi, sp = po.material_update(cfg, 2, eps, g)
+    tr = eps[:3].sum(); dev = eps[:3] - tr / 3
+    assert np.allclose(sig[:3], K * tr + g * 2 * G * dev, rtol=1e-13)
+    assert abs(sig[3] - g * G * eps[3]) < 1e-15
+    assert abs(psi - G * (dev @ dev + 0.5 * eps[3] ** 2)) < 1e-16
+    eps = -eps
+    sig, D, psi, sp = po.material_update(cfg, 2, eps, g)
+    assert np.allclose(sig[:3], g * (K * -tr - 2 * G * dev), rtol=1e-13)
+    assert abs(psi - (0.5 * K * tr * tr + G * (dev @ dev + 0.5 * eps[3] ** 2))) < 1e-15
+    for m in (np_ref.amor(2, 100.0, 0.2, eps, g),):
+        assert np.allclose(m[0], sig, rtol=1e-14) and np.allclose(m[1], D, rtol=1e-14)
+
+
+@pytest.mark.parametrize("rank", [2, 3])
+def test_miehe_properties(rank):
+    cfg = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE, po.MIEHE, young=210.0, poisson=0.3)
+    K = 210 / (3 * 0.4); G = 210 / 2.6; lam = K - 0.666666667 * G
+    n = 4 if rank == 2 else 6
+    rng = np.random.default_rng(3)
+    # all-tension state: sigma+ = full elastic stress, sigma = g sigma+
+    eps = np.array([2e-3, 1e-3, 0.0, 0.4e-3, 0.0, 0.0])[:n]
+    if rank == 3:
+        eps[2] = 1.5e-3; eps[4] = 0.2e-3; eps[5] = -0.3e-3
+    sig, D, psi, sp = po.material_update(cfg, rank, eps, 0.5)
+    tr = eps[:3].sum()
+    el = lam * tr * np.array([1, 1, 1, 0, 0, 0])[:n] + 2 * G * np.concatenate([eps[:3], 0.5 * eps[3:]])
+    if rank == 2:
+        # eps_zz = 0 eigenvalue: diag uses eigVal > 0 (strict) so nothing changes for sigma
+        pass
+    assert np.allclose(sp, el, rtol=1e-12, atol=1e-15)
+    assert np.allclose(sig, 0.5 * el, rtol=1e-12, atol=1e-15)
+    # mixed state: tangent = d sigma / d eps (finite differences), psi consistent with sigma+
+    for _ in range(5):
+        eps = rng.uniform(-1, 1, n) * 1e-3
+        if rank == 2:
+            eps[2] = 0.0
+        g = 0.37
+        sig, D, psi, sp = po.material_update(cfg, rank, eps, g)
+        h = 1e-9
+        cols = [c for c in range(n) if not (rank == 2 and c == 2)]
+        for c in cols:
+            e1 = eps.copy(); e1[c] += h; e2 = eps.copy(); e2[c] -= h
+            s1 = po.material_update(cfg, rank, e1, g)[0]; s2 = po.material_update(cfg, rank, e2, g)[0]
+            fd = (s1 - s2) / (2 * h)
+            assert np.allclose(fd, D[:, c], rtol=2e-5, atol=2e-5 * np.abs(D).max())
+            p1 = po.material_update(cfg, rank, e1, g)[2]; p2 = po.material_update(cfg, rank, e2, g)[2]
+            assert abs((p1 - p2) / (2 * h) - sp[c]) < 1e-5 * np.abs(sp).max() + 1e-9
+
+
+def test_bourdin_kat4():
+    """KAT-4: AT2 + Bourdin, uniform strain, phi = 0."""
+    coords, conn = meshgen.grid_quad4(3, 3)
+    coords = meshgen.distort(coords, conn, 0.1)
+    nn = coords.shape[0]
+    gc, l0 = 2.7, 0.4
+    cfg = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE, po.BOURDIN, young=10.0, poisson=0.2, gc=gc, l0=l0)
+    rp, ci = po.pattern(nn, conn, 3, 2)
+    A = np.array([[1e-2, 0.0], [0.0, -0.3e-2]])
+    s = np.zeros((nn, 3)); s[:, :2] = coords @ A.T
+    out = po.assemble(cfg, coords, conn, rp, ci, s.ravel())
+    D = np_ref.hooke(2, 0, 10.0, 0.2)
+    eps = np.array([1e-2, -0.3e-2, 0, 0]); psi = 0.5 * eps @ D @ eps
+    # lumped nodal areas from a unit-phi "mass": assemble via K_phiphi row sums / (gc/l0 + 2 psi)
+    K = csr_dense(rp, ci, out["K"])
+    Kpp = K[2::3, 2::3]
+    f_phi = out["f"][2::3]
+    area = Kpp.sum(1) / (gc / l0 + 2 * psi)                 # grad terms sum to zero over columns
+    x = coords[conn]                                         # shoelace area of every quad
+    tot = 0.5 * np.abs((x[:, :, 0] * np.roll(x[:, :, 1], -1, 1) - np.roll(x[:, :, 0], -1, 1) * x[:, :, 1]).sum(1)).sum()
+    assert abs(area.sum() - tot) < 1e-12
+    assert np.allclose(f_phi, -2 * psi * area, rtol=1e-11)
+    assert np.allclose(out["hist_new"], psi, rtol=1e-12)
+    assert np.abs(K[0::3, 2::3]).max() == 0.0               # keepOffDiags=false: u-phi never written
+
+
+@pytest.mark.parametrize("material", [po.AMOR, po.BOURDIN, po.MIEHE])
+def test_tangent_finite_difference(material):
+    """KAT-5: K = d f_int / d state with keepOffDiags=true, history inactive (H0 = 0 < Psi)."""
+    coords, conn = meshgen.grid_quad4(2, 2)
+    coords = meshgen.distort(coords, conn, 0.1)
+    nn = coords.shape[0]
+    cfg = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE, material, young=210.0, poisson=0.3, gc=2.7e-3, l0=0.3,
+                         keep_off_diags=1)
+    rp, ci = po.pattern(nn, conn, 3, 2)
+    st = meshgen.smooth_state(coords, 3, amp=5e-3, noise=1e-4, l0=0.3)
+    out = po.assemble(cfg, coords, conn, rp, ci, st)
+    K = csr_dense(rp, ci, out["K"])
+    h = 1e-7
+    for j in range(st.size):
+        sp = st.copy(); sp[j] += h; sm = st.copy(); sm[j] -= h
+        fp = po.assemble(cfg, coords, conn, rp, ci, sp, want_K=False)["f"]
+        fm = po.assemble(cfg, coords, conn, rp, ci, sm, want_K=False)["f"]
+        fd = (fp - fm) / (2 * h)
+        assert np.allclose(fd, K[:, j], rtol=1e-5, atol=1e-6 * np.abs(K).max()), j
+
+
+@pytest.mark.parametrize("shape,material,keep", [(po.QUAD4_G2, po.AMOR, 1), (po.QUAD4_G2, po.BOURDIN, 0),
+                                                 (po.TRI3_G1, po.AMOR, 1), (po.HEX8_G2, po.AMOR, 1)])
+def test_oracle_vs_numpy_restatement(shape, material, keep):
+    rank, npe, nip, _ = po.shape_info(shape)
+    coords, conn = GRID[shape]()
+    coords = meshgen.distort(coords, conn, 0.12)
+    nn = coords.shape[0]; nd = rank + 1
+    E, nu, gc, l0 = 210.0, 0.3, 2.7e-3, 0.2
+    cfg = po.make_config(shape, po.PHASE_FRACTURE, material, young=E, poisson=nu, gc=gc, l0=l0, keep_off_diags=keep)
+    rp, ci = po.pattern(nn, conn, nd, rank)
+    st = meshgen.smooth_state(coords, nd, amp=5e-3, noise=1e-4, l0=0.3)
+    rng = np.random.default_rng(5)
+    H0 = rng.uniform(0, 2e-3, conn.shape[0] * nip)
+    out = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=H0)
+    N, dN, w = po.shape_tables(shape)
+    mat = (lambda e, g: np_ref.amor(rank, E, nu, e, g)) if material == po.AMOR else \
+          (lambda e, g: np_ref.bourdin(rank, 0, E, nu, e, g))
+    ndof = nn * nd
+    K = np.zeros((ndof, ndof)); f = np.zeros(ndof); Hn = np.zeros_like(H0)
+    S = st.reshape(nn, nd)
+    for e, c in enumerate(conn):
+        ud = np.array([[n * nd + i for i in range(rank)] for n in c]).ravel(); pd = c * nd + rank
+        K1, K2, K3, K4, f1, f2, hn = np_ref.element_pf(coords[c], N, dN, w, S[c, :rank].ravel(), S[c, rank],
+                                                       H0[e * nip:(e + 1) * nip], mat,
+                                                       (gc, l0, 2.0, 0.0, 2.0, 2.0, -0.5, 0.0), keep)
+        K[np.ix_(ud, ud)] += K1; K[np.ix_(pd, pd)] += K4
+        K[np.ix_(ud, pd)] += K2; K[np.ix_(pd, ud)] += K3
+        f[ud] += f1; f[pd] += f2; Hn[e * nip:(e + 1) * nip] = hn
+    Ko = csr_dense(rp, ci, out["K"])
+    assert np.allclose(Ko, K, rtol=0, atol=1e-12 * np.abs(K).max())
+    assert np.allclose(out["f"], f, rtol=0, atol=1e-12 * np.abs(f).max())
+    assert np.allclose(out["hist_new"], Hn, rtol=1e-13)
+
+
+def test_ext_variants_reduce_to_base_and_penalty():
+    """PhaseFractureExt with phi0 = phi00 = phi, dt0 = 0 has g(phiEx) = g(phi): K1, f match PhaseFracture
+    (history off); the penalty adds beta terms only where phi0 - phi > 1e-15."""
+    coords, conn = meshgen.grid_quad4(3, 3)
+    nn = coords.shape[0]
+    kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2)
+    base = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE, po.AMOR, keep_off_diags=1, **kw)
+    ext = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE_EXT, po.AMOR, beta=6500.0, **kw)
+    rp, ci = po.pattern(nn, conn, 3, 2)
+    st = meshgen.smooth_state(coords, 3, amp=5e-3, noise=1e-4, l0=0.3)
+    a = po.assemble(base, coords, conn, rp, ci, st)
+    b = po.assemble(ext, coords, conn, rp, ci, st, state0=st, state00=st, dt=1.0, dt0=0.0)
+    Ka = csr_dense(rp, ci, a["K"]); Kb = csr_dense(rp, ci, b["K"])
+    Ka[0::3, 2::3] = 0; Ka[1::3, 2::3] = 0                  # Ext never assembles K2
+    assert np.allclose(Ka, Kb, atol=1e-13 * np.abs(Ka).max())
+    assert np.allclose(a["f"], b["f"], atol=1e-13 * np.abs(a["f"]).max())
+    st0 = st.copy(); st0[2::3] += 0.01                      # phi decreased everywhere -> penalty on
+    c = po.assemble(ext, coords, conn, rp, ci, st, state0=st0, state00=st0, dt=1.0, dt0=1.0)
+    Kc = csr_dense(rp, ci, c["K"])
+    extra = (Kc - Kb)[2::3, 2::3]
+    g = 2.7e-3 / (2.0 * 0.2)
+    assert extra.sum() > 0
+    # ExtIt: err_ext = sum (pf - pfEx)^2 over ips
+    extit = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE_EXTIT, po.AMOR, beta=6500.0, **kw)
+    d = po.assemble(extit, coords, conn, rp, ci, st, state0=st, state00=st0)
+    assert abs(d["err_ext"] - conn.shape[0] * 4 * 1e-4) < 1e-12
+    assert g > 0
+
+
+def test_pattern_kinds():
+    coords, conn = meshgen.grid_quad4(4, 3)
+    nn = coords.shape[0]
+    rp, ci = po.pattern(nn, conn, 3, 2, po.PATTERN_FULL)
+    pairs = (3 * 4 + 1) * (3 * 3 + 1)
+    assert rp[-1] == 9 * pairs
+    rpw, ciw = po.pattern(nn, conn, 3, 2, po.PATTERN_WRITTEN, 0)
+    assert rpw[-1] == 5 * pairs
+    rpe, cie = po.pattern(nn, conn, 3, 2, po.PATTERN_WRITTEN, 2)
+    assert rpe[-1] == 7 * pairs
+    for r in range(len(rp) - 1):
+        assert np.all(np.diff(ci[rp[r]:rp[r + 1]]) > 0)
