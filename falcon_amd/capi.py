@@ -1,0 +1,188 @@
+"""ctypes binding of libfalcon_assemble.so (include/falcon_assemble.h) + a thin torch-backed helper.
+
+PyTorch is used only for device memory and streams; the arithmetic is in the HIP library.  There is
+no CPU fallback: if the library is missing or no GPU is present the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfalcon_assemble.so")
+
+# enums of include/falcon_assemble.h
+TRI3_G1, TRI3_G3, QUAD4_G2, QUAD8_G3, QUAD8_G2, TRI6_G3, HEX8_G2, HEX20_G3, HEX20_G2 = range(9)
+LINEAR_ELASTICITY, PHASE_FRACTURE, PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT = range(4)
+HOOKE, AMOR_PHASE, BOURDIN_PHASE, MIEHE_PHASE = range(4)
+PLANE_STRAIN, PLANE_STRESS = 0, 1
+AT1, AT2, CZM_LINEAR, CZM_EXPONENTIAL, CZM_CORNELISSEN, CZM_HYPERBOLIC = range(6)
+PATTERN_FULL, PATTERN_WRITTEN = 0, 1
+ACCUMULATE, OVERWRITE, STORE_STRAIN, FORCE_GENERIC = 0, 1, 2, 4
+
+SHAPE_INFO = {  # shape id -> (rank, npe, nip)
+    TRI3_G1: (2, 3, 1), TRI3_G3: (2, 3, 3), QUAD4_G2: (2, 4, 4), QUAD8_G3: (2, 8, 9), QUAD8_G2: (2, 8, 4),
+    TRI6_G3: (2, 6, 3), HEX8_G2: (3, 8, 8), HEX20_G3: (3, 20, 27), HEX20_G2: (3, 20, 8)}
+
+
+class FaError(RuntimeError):
+    pass
+
+
+class Problem(C.Structure):
+    _fields_ = [("shape", C.c_int32), ("model", C.c_int32), ("material", C.c_int32), ("state", C.c_int32),
+                ("young", C.c_double), ("poisson", C.c_double),
+                ("frac_type", C.c_int32),
+                ("gc", C.c_double), ("l0", C.c_double), ("sigma_t", C.c_double), ("beta", C.c_double),
+                ("keep_off_diags", C.c_int32),
+                ("nnode", C.c_int64), ("coords", C.c_void_p),
+                ("nel", C.c_int64), ("conn", C.c_void_p),
+                ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("node_dofs", C.c_void_p),
+                ("ndof", C.c_int64), ("pattern_kind", C.c_int32), ("device", C.c_int32)]
+
+
+class AssembleArgs(C.Structure):
+    _fields_ = [("state", C.c_void_p), ("state0", C.c_void_p), ("state00", C.c_void_p),
+                ("dt", C.c_double), ("dt0", C.c_double),
+                ("K_values", C.c_void_p), ("f_int", C.c_void_p), ("err_ext", C.c_void_p),
+                ("flags", C.c_int32), ("stream", C.c_void_p)]
+
+
+EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_nip_total", "fa_ndof_per_node",
+           "fa_strain_rows", "fa_uses_row_kernel", "fa_psi0", "fa_pattern_host", "fa_pattern_device",
+           "fa_assemble", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
+           "fa_history_device", "fa_get_strain_cache"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FaError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.fa_create.argtypes = [C.POINTER(Problem), C.POINTER(vp)]
+        L.fa_destroy.argtypes = [vp]; L.fa_destroy.restype = None
+        L.fa_last_error.restype = C.c_char_p
+        for name in ("fa_ndof", "fa_nnz", "fa_nip_total"):
+            getattr(L, name).argtypes = [vp]; getattr(L, name).restype = C.c_int64
+        for name in ("fa_ndof_per_node", "fa_strain_rows", "fa_uses_row_kernel"):
+            getattr(L, name).argtypes = [vp]; getattr(L, name).restype = C.c_int32
+        L.fa_psi0.argtypes = [vp]; L.fa_psi0.restype = C.c_double
+        L.fa_pattern_host.argtypes = [vp, vp, vp]
+        L.fa_pattern_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+        L.fa_assemble.argtypes = [vp, C.POINTER(AssembleArgs)]
+        L.fa_assemble_host.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, C.c_int32]
+        L.fa_commit.argtypes = [vp]
+        L.fa_get_history.argtypes = [vp, C.c_int32, vp]
+        L.fa_set_history.argtypes = [vp, C.c_int32, vp]
+        L.fa_history_device.argtypes = [vp, C.c_int32]; L.fa_history_device.restype = vp
+        L.fa_get_strain_cache.argtypes = [vp, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise FaError(f"falcon_assemble error {rc}: {lib().fa_last_error().decode()}")
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Assembler:
+    """One model instance on one GPU (the object a Jive shim would own)."""
+
+    def __init__(self, shape, model, material, coords, conn, *, state=PLANE_STRAIN, young=210e3, poisson=0.3,
+                 frac_type=AT2, gc=2.7, l0=0.015, sigma_t=0.0, beta=6500.0, keep_off_diags=False,
+                 row_ptr=None, col_idx=None, node_dofs=None, ndof=0, pattern_kind=PATTERN_FULL, device=0):
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        conn = np.ascontiguousarray(conn, dtype=np.int32)
+        rank, npe, nip = SHAPE_INFO[shape]
+        if coords.ndim != 2 or coords.shape[1] != rank:
+            raise FaError(f"shape has invalid rank: {coords.shape[1] if coords.ndim == 2 else '?'} (should be {rank})")
+        if conn.ndim != 2 or (conn.size and conn.shape[1] != npe):
+            raise FaError(f"elements must have {npe} nodes")
+        self._keep = [coords, conn]
+        if row_ptr is not None:
+            row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+            col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+        if node_dofs is not None:
+            node_dofs = np.ascontiguousarray(node_dofs, dtype=np.int64)
+        self._keep += [row_ptr, col_idx, node_dofs]
+        p = Problem(shape, model, material, state, young, poisson, frac_type, gc, l0, sigma_t, beta,
+                    int(bool(keep_off_diags)), coords.shape[0], _np_ptr(coords), conn.shape[0], _np_ptr(conn),
+                    _np_ptr(row_ptr), _np_ptr(col_idx), _np_ptr(node_dofs), ndof, pattern_kind, device)
+        self.h = C.c_void_p()
+        _check(lib().fa_create(C.byref(p), C.byref(self.h)))
+        L = lib()
+        self.shape, self.model, self.material, self.device = shape, model, material, device
+        self.rank, self.npe, self.nip = rank, npe, nip
+        self.nnode, self.nel = coords.shape[0], conn.shape[0]
+        self.ndof, self.nnz = L.fa_ndof(self.h), L.fa_nnz(self.h)
+        self.nip_total, self.ndofpn = L.fa_nip_total(self.h), L.fa_ndof_per_node(self.h)
+        self.strain_rows = L.fa_strain_rows(self.h)
+        self.uses_row_kernel = bool(L.fa_uses_row_kernel(self.h))
+        self.psi0 = L.fa_psi0(self.h)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            lib().fa_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def pattern(self):
+        rp = np.empty(self.ndof + 1, dtype=np.int64); ci = np.empty(self.nnz, dtype=np.int32)
+        _check(lib().fa_pattern_host(self.h, _np_ptr(rp), _np_ptr(ci)))
+        return rp, ci
+
+    # ---- device path (torch tensors on cuda:device, float64) ----
+    def assemble(self, state, K=None, f=None, *, state0=None, state00=None, dt=0.0, dt0=0.0, err_ext=None,
+                 flags=ACCUMULATE, stream=None):
+        import torch
+        def ptr(t, n):
+            if t is None:
+                return None
+            assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() >= n, "bad device vector"
+            return t.data_ptr()
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        a = AssembleArgs(ptr(state, self.ndof), ptr(state0, self.ndof), ptr(state00, self.ndof), dt, dt0,
+                         ptr(K, self.nnz), ptr(f, self.ndof), ptr(err_ext, 1), flags, stream)
+        _check(lib().fa_assemble(self.h, C.byref(a)))
+
+    # ---- host path (numpy vectors; H2D + assemble + D2H inside the library) ----
+    def assemble_host(self, state, K=None, f=None, *, state0=None, state00=None, dt=0.0, dt0=0.0,
+                      want_err=False, flags=ACCUMULATE):
+        state = np.ascontiguousarray(state, dtype=np.float64)
+        assert state.size == self.ndof
+        if f is None:
+            f = np.zeros(self.ndof)
+        s0 = None if state0 is None else np.ascontiguousarray(state0, dtype=np.float64)
+        s00 = None if state00 is None else np.ascontiguousarray(state00, dtype=np.float64)
+        err = np.zeros(1)
+        _check(lib().fa_assemble_host(self.h, _np_ptr(state), _np_ptr(s0), _np_ptr(s00), dt, dt0, _np_ptr(K),
+                                      _np_ptr(f), _np_ptr(err) if want_err else None, flags))
+        return K, f, float(err[0])
+
+    def commit(self):
+        _check(lib().fa_commit(self.h))
+
+    def get_history(self, which):
+        out = np.empty(self.nip_total)
+        _check(lib().fa_get_history(self.h, which, _np_ptr(out)))
+        return out
+
+    def set_history(self, which, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        assert v.size == self.nip_total
+        _check(lib().fa_set_history(self.h, which, _np_ptr(v)))
+
+    def get_strain_cache(self):
+        out = np.empty((self.nip_total, self.strain_rows))
+        _check(lib().fa_get_strain_cache(self.h, _np_ptr(out)))
+        return out

@@ -1,0 +1,577 @@
+// fa_api.hip -- host side of libfalcon_assemble.so: the C ABI declared in include/falcon_assemble.h.
+//
+// Set-up (fa_create) replaces what the reference's model constructors obtain from Jive
+// (PhaseFractureModel.cpp:82-267): element group connectivity, DOF space, "FEM" matrix pattern;
+// plus the topology the row-gather kernel needs (inverse connectivity, neighbour lists, per-element
+// column positions, workgroup partition).  Everything lives in HBM afterwards.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/falcon_assemble.h"
+#include "fa_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+fa_status fail(fa_status code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do { hipError_t _e = (expr);                                                                     \
+       if (_e != hipSuccess) return fail(FA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } while (0)
+
+template <class F>
+void parallel_for(int64_t n, F&& body) {
+  unsigned hw = std::thread::hardware_concurrency();
+  int nt = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, n / 4096));
+  if (nt <= 1) { body(0, n); return; }
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; t++) {
+    const int64_t b = t * chunk, e = std::min(n, b + chunk);
+    if (b >= e) break;
+    th.emplace_back([&body, b, e] { body(b, e); });
+  }
+  for (auto& x : th) x.join();
+}
+
+// ---- shape tables (IShapeFactory stand-in): standard isoparametric elements, tensor Gauss rules ----
+struct ShapeTab { int rank = 0, npe = 0, nip = 0; std::vector<double> N, dN, w; };
+
+void gauss_line(int n, double* x, double* w) {
+  if (n == 1) { x[0] = 0; w[0] = 2; }
+  else if (n == 2) { x[0] = -std::sqrt(1.0 / 3.0); x[1] = -x[0]; w[0] = w[1] = 1; }
+  else { x[0] = -std::sqrt(3.0 / 5.0); x[1] = 0; x[2] = -x[0]; w[0] = w[2] = 5.0 / 9.0; w[1] = 8.0 / 9.0; }
+}
+
+bool make_shape(int id, ShapeTab& s) {
+  auto alloc = [&](int rank, int npe, int nip) {
+    s.rank = rank; s.npe = npe; s.nip = nip;
+    s.N.assign((size_t)nip * npe, 0.0); s.dN.assign((size_t)nip * npe * rank, 0.0); s.w.assign(nip, 0.0);
+  };
+  double gx[3], gw[3];
+  switch (id) {
+    case FA_TRI3_G1: {
+      alloc(2, 3, 1);
+      const double xi = 1.0 / 3.0, et = 1.0 / 3.0;
+      s.N = { 1 - xi - et, xi, et };
+      s.dN = { -1, -1, 1, 0, 0, 1 };
+      s.w = { 0.5 };
+      return true;
+    }
+    case FA_QUAD4_G2: {
+      alloc(2, 4, 4);
+      gauss_line(2, gx, gw);
+      const int sx[4] = { -1, 1, 1, -1 }, sy[4] = { -1, -1, 1, 1 };
+      for (int iy = 0; iy < 2; iy++) for (int ix = 0; ix < 2; ix++) {
+        const int ip = iy * 2 + ix;
+        for (int a = 0; a < 4; a++) {
+          s.N[ip * 4 + a] = 0.25 * (1 + sx[a] * gx[ix]) * (1 + sy[a] * gx[iy]);
+          s.dN[(ip * 4 + a) * 2 + 0] = 0.25 * sx[a] * (1 + sy[a] * gx[iy]);
+          s.dN[(ip * 4 + a) * 2 + 1] = 0.25 * sy[a] * (1 + sx[a] * gx[ix]);
+        }
+        s.w[ip] = gw[ix] * gw[iy];
+      }
+      return true;
+    }
+    case FA_HEX8_G2: {
+      alloc(3, 8, 8);
+      gauss_line(2, gx, gw);
+      const int sx[8] = { -1, 1, 1, -1, -1, 1, 1, -1 }, sy[8] = { -1, -1, 1, 1, -1, -1, 1, 1 },
+                sz[8] = { -1, -1, -1, -1, 1, 1, 1, 1 };
+      for (int iz = 0; iz < 2; iz++) for (int iy = 0; iy < 2; iy++) for (int ix = 0; ix < 2; ix++) {
+        const int ip = (iz * 2 + iy) * 2 + ix;
+        for (int a = 0; a < 8; a++) {
+          const double fx = 1 + sx[a] * gx[ix], fy = 1 + sy[a] * gx[iy], fz = 1 + sz[a] * gx[iz];
+          s.N[ip * 8 + a] = 0.125 * fx * fy * fz;
+          s.dN[(ip * 8 + a) * 3 + 0] = 0.125 * sx[a] * fy * fz;
+          s.dN[(ip * 8 + a) * 3 + 1] = 0.125 * sy[a] * fx * fz;
+          s.dN[(ip * 8 + a) * 3 + 2] = 0.125 * sz[a] * fx * fy;
+        }
+        s.w[ip] = gw[ix] * gw[iy] * gw[iz];
+      }
+      return true;
+    }
+  }
+  return false;
+}
+
+fa::launch_fn launcher_for(int shape) {
+  switch (shape) {
+    case FA_TRI3_G1:  return fa::launch_tri3_g1;
+    case FA_QUAD4_G2: return fa::launch_quad4_g2;
+    case FA_HEX8_G2:  return fa::launch_hex8_g2;
+  }
+  return nullptr;
+}
+
+template <class T>
+fa_status upload(T** dst, const T* src, size_t n) {
+  HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+  if (n) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return FA_OK;
+}
+
+__global__ void fill_kernel(double* p, int64_t n, double v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// deterministic sum of the per-workgroup partials of errExt_
+__global__ void reduce_err_kernel(const double* part, int n, double* out) {
+  __shared__ double s[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) *out = s[0];
+}
+
+}  // namespace
+
+struct fa_ctx {
+  fa_problem prob{};
+  int rank = 0, npe = 0, nip = 0, str = 0, ndofpn = 0, fam = 0, srows = 0;
+  int64_t nnode = 0, nel = 0, ndof = 0, nnz = 0;
+  bool rows_path = false, own_pattern = false;
+  int nwg = 0, max_valence = 0, ngrid_generic = 0;
+  fa::launch_fn launch = nullptr;
+  fa::Params P{};
+  // device
+  int32_t* d_conn = nullptr; double* d_coords = nullptr; int64_t* d_row_ptr = nullptr; int32_t* d_col_idx = nullptr;
+  int64_t* d_node_dofs = nullptr; int32_t* d_n2e_ptr = nullptr; int32_t* d_n2e_ent = nullptr; uint8_t* d_pos = nullptr;
+  int32_t* d_wg_start = nullptr; double* d_tab = nullptr;
+  double* d_hist[2] = { nullptr, nullptr };   // [0] preHist_, [1] newHist_
+  double* d_strain = nullptr; double* d_err_part = nullptr;
+  // staging for fa_assemble_host
+  double *s_state = nullptr, *s_state0 = nullptr, *s_state00 = nullptr, *s_K = nullptr, *s_f = nullptr, *s_err = nullptr;
+  std::vector<double> h_tmp;
+};
+
+extern "C" const char* fa_last_error(void) { return g_err.c_str(); }
+
+extern "C" void fa_destroy(fa_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->prob.device);
+  void* ptrs[] = { c->d_conn, c->d_coords, c->d_row_ptr, c->d_col_idx, c->d_node_dofs, c->d_n2e_ptr, c->d_n2e_ent,
+                   c->d_pos, c->d_wg_start, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part,
+                   c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err };
+  for (void* p : ptrs) if (p) hipFree(p);
+  delete c;
+}
+
+static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
+  c->prob = *p;
+  ShapeTab sh;
+  if (!make_shape(p->shape, sh))
+    return fail(FA_ERR_UNSUPPORTED, "shape id %d has no gfx950 kernel yet", p->shape);
+  c->launch = launcher_for(p->shape);
+  c->rank = sh.rank; c->npe = sh.npe; c->nip = sh.nip; c->str = (sh.rank == 2) ? 4 : 6;
+  if (p->model < FA_LINEAR_ELASTICITY || p->model > FA_PHASE_FRACTURE_EXTIT) return fail(FA_ERR_ARG, "invalid model %d", p->model);
+  const bool pf = p->model != FA_LINEAR_ELASTICITY;
+  c->ndofpn = pf ? sh.rank + 1 : sh.rank;
+  c->srows = pf ? c->str + 1 : c->str;
+  // material <-> model pairing (PhaseFractureModel.cpp:193-194 dynamicCast<PhaseFractureMaterial>)
+  if (!pf && p->material != FA_HOOKE) return fail(FA_ERR_ARG, "LinearElasticity needs material Hooke");
+  if (pf && p->material == FA_HOOKE) return fail(FA_ERR_ARG, "phase-field models need a PhaseFractureMaterial");
+  if (p->material == FA_MIEHE_PHASE) return fail(FA_ERR_UNSUPPORTED, "MiehePhase has no gfx950 kernel yet");
+  if (p->material < FA_HOOKE || p->material > FA_MIEHE_PHASE) return fail(FA_ERR_ARG, "Invalid material: %d", p->material);
+  c->fam = !pf ? fa::FAM_LE : fa::FAM_PF_ISO;
+  if (sh.rank == 2 && p->state != FA_PLANE_STRAIN && p->state != FA_PLANE_STRESS)
+    return fail(FA_ERR_ARG, "unexpected rank/state");     // HookeMaterial.cpp:262-265
+  if (p->nnode <= 0 || p->nel < 0 || !p->coords || (!p->conn && p->nel)) return fail(FA_ERR_ARG, "empty mesh arrays");
+  if (p->nnode > 2000000000LL || p->nel * sh.npe > 2000000000LL) return fail(FA_ERR_UNSUPPORTED, "mesh too large for 32-bit topology");
+  const int64_t nnode = p->nnode, nel = p->nel;
+  const int npe = sh.npe, nd = c->ndofpn, rank = sh.rank;
+  c->nnode = nnode; c->nel = nel;
+  for (int64_t k = 0; k < nel * npe; k++)
+    if (p->conn[k] < 0 || p->conn[k] >= nnode) return fail(FA_ERR_ARG, "connectivity entry %lld out of range", (long long)k);
+
+  fa::Params& P = c->P;
+  // ---- fracture constants (PhaseFractureModel.cpp:296-355) ----
+  {
+    const double E = p->young, gc = p->gc, l0 = p->l0, sT = p->sigma_t;
+    double cw = 2, eta = 0, pe = 2, a1 = 2, a2 = -0.5, a3 = 0, psi0 = 0;
+    if (pf) {
+      switch (p->frac_type) {
+        case FA_AT1: cw = 8.0 / 3.0; eta = 1.0; psi0 = (3. * gc) / (16. * l0); break;
+        case FA_AT2: break;
+        case FA_CZM_LINEAR: cw = 3.14159265359; eta = 2.0; a1 = (4.0 * E * gc) / (cw * l0 * sT * sT);
+                            psi0 = 0.5 * (sT * sT) / E; break;
+        case FA_CZM_EXPONENTIAL: cw = 3.14159265359; eta = 2.0; pe = 2.5; a1 = (4.0 * E * gc) / (cw * l0 * sT * sT);
+                            a2 = ::pow(2.0, 5.0 / 3.0) - 3.0; psi0 = 0.5 * (sT * sT) / E; break;
+        case FA_CZM_CORNELISSEN: cw = 3.14159265359; eta = 2.0; a1 = (4.0 * E * gc) / (cw * l0 * sT * sT);
+                            a2 = 1.3868; a3 = 0.6567; psi0 = 0.5 * (sT * sT) / E; break;
+        case FA_CZM_HYPERBOLIC: cw = 3.14159265359; eta = 2.0; pe = 4.0; a1 = (4.0 * E * gc) / (cw * l0 * sT * sT);
+                            a2 = ::pow(2.0, 7.0 / 3.0) - 4.5; psi0 = 0.5 * (sT * sT) / E; break;
+        default: return fail(FA_ERR_ARG, "unexpected definition of fracture type!!! Supported types include: "
+                                         "at1, at2, czmLinear, czmExponential, czmCornelissen, czmHyperbolic");
+      }
+    }
+    P.ptype = (pe == 2.0) ? 0 : (pe == 2.5 ? 1 : 2);
+    P.gcl = gc / (cw * l0); P.c2 = 2.0 * gc * l0 / cw;
+    P.eta = eta; P.a1 = a1; P.a2 = a2; P.a3 = a3; P.psi0 = psi0; P.beta = p->beta;
+    // elastic constants (AmorPhaseMaterial.cpp:85-86, MiehePhaseMaterial.cpp:97-99, HookeMaterial.cpp:202-267)
+    const double nu = p->poisson;
+    P.Kb = E / (3.0 * (1.0 - 2.0 * nu)); P.G = E / (2.0 * (1.0 + nu)); P.lmda = P.Kb - 0.666666667 * P.G;
+    if (rank == 3 || p->state == FA_PLANE_STRAIN) {
+      const double a = E / ((1.0 + nu) * (1.0 - 2.0 * nu));
+      P.hd0 = a * (1.0 - nu); P.hd1 = a * nu; P.hd3 = a * (0.5 * (1.0 - 2.0 * nu));
+    } else {
+      const double a = E / (1.0 - nu * nu);
+      P.hd0 = a; P.hd1 = a * nu; P.hd3 = a * 0.5 * (1.0 - nu);
+    }
+  }
+  P.model = p->model; P.material = p->material; P.ndofpn = nd; P.nnode = nnode; P.nel = nel;
+  P.keep2 = (p->model == FA_PHASE_FRACTURE) && p->keep_off_diags;
+  P.keep3 = (p->model == FA_PHASE_FRACTURE) ? (p->keep_off_diags != 0) : (pf ? 1 : 0);
+
+  // ---- inverse connectivity, element-ascending per node ----
+  std::vector<int32_t> n2e_ptr(nnode + 1, 0), n2e_ent((size_t)nel * npe);
+  for (int64_t k = 0; k < nel * npe; k++) n2e_ptr[p->conn[k] + 1]++;
+  int maxval = 0;
+  for (int64_t n = 0; n < nnode; n++) { maxval = std::max(maxval, n2e_ptr[n + 1]); n2e_ptr[n + 1] += n2e_ptr[n]; }
+  {
+    std::vector<int32_t> fill(n2e_ptr.begin(), n2e_ptr.end() - 1);
+    for (int64_t k = 0; k < nel * npe; k++) n2e_ent[fill[p->conn[k]]++] = (int32_t)k;   // k = e*npe + la
+  }
+  c->max_valence = maxval;
+
+  // ---- sorted neighbour lists ----
+  std::vector<int64_t> nb_ptr(nnode + 1, 0);
+  {
+    std::vector<int32_t> cnt(nnode, 0);
+    bool overflow = false;
+    parallel_for(nnode, [&](int64_t b, int64_t e) {
+      std::vector<int32_t> tmp;
+      for (int64_t n = b; n < e; n++) {
+        tmp.clear();
+        for (int32_t k = n2e_ptr[n]; k < n2e_ptr[n + 1]; k++) {
+          const int32_t* cn = p->conn + (int64_t)(n2e_ent[k] / npe) * npe;
+          tmp.insert(tmp.end(), cn, cn + npe);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        cnt[n] = (int32_t)(std::unique(tmp.begin(), tmp.end()) - tmp.begin());
+        if (cnt[n] > 255) overflow = true;
+      }
+    });
+    if (overflow) return fail(FA_ERR_UNSUPPORTED, "a node has more than 255 neighbours");
+    for (int64_t n = 0; n < nnode; n++) nb_ptr[n + 1] = nb_ptr[n] + cnt[n];
+  }
+  std::vector<int32_t> nb((size_t)nb_ptr[nnode]);
+  parallel_for(nnode, [&](int64_t b, int64_t e) {
+    std::vector<int32_t> tmp;
+    for (int64_t n = b; n < e; n++) {
+      tmp.clear();
+      for (int32_t k = n2e_ptr[n]; k < n2e_ptr[n + 1]; k++) {
+        const int32_t* cn = p->conn + (int64_t)(n2e_ent[k] / npe) * npe;
+        tmp.insert(tmp.end(), cn, cn + npe);
+      }
+      std::sort(tmp.begin(), tmp.end());
+      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+      std::copy(tmp.begin(), tmp.end(), nb.begin() + nb_ptr[n]);
+    }
+  });
+  std::vector<uint8_t> pos((size_t)nel * npe * npe);
+  parallel_for(nel, [&](int64_t b, int64_t e) {
+    for (int64_t el = b; el < e; el++) {
+      const int32_t* cn = p->conn + el * npe;
+      for (int la = 0; la < npe; la++) {
+        const int32_t* lo = nb.data() + nb_ptr[cn[la]];
+        const int32_t* hi = nb.data() + nb_ptr[cn[la] + 1];
+        for (int lb = 0; lb < npe; lb++)
+          pos[(el * npe + la) * npe + lb] = (uint8_t)(std::lower_bound(lo, hi, cn[lb]) - lo);
+      }
+    }
+  });
+
+  // ---- canonical pattern: dof = node*ndofpn + type, rows column-sorted; type-pair mask ----
+  auto canonical = [&](int kind, int (&cnt)[4], int (&off)[4][4], std::vector<int64_t>& rp, std::vector<int32_t>* ci) {
+    for (int i = 0; i < 4; i++) { cnt[i] = 0; for (int j = 0; j < 4; j++) off[i][j] = -1; }
+    for (int i = 0; i < nd; i++) for (int j = 0; j < nd; j++) {
+      bool on = true;
+      if (kind == FA_PATTERN_WRITTEN && pf) {
+        const bool iu = i < rank, ju = j < rank;
+        if (iu && !ju) on = P.keep2; else if (!iu && ju) on = P.keep3;
+      }
+      if (on) off[i][j] = cnt[i]++;
+    }
+    rp.assign((size_t)nnode * nd + 1, 0);
+    for (int64_t n = 0; n < nnode; n++)
+      for (int i = 0; i < nd; i++) rp[n * nd + i + 1] = rp[n * nd + i] + (nb_ptr[n + 1] - nb_ptr[n]) * cnt[i];
+    if (ci) {
+      ci->resize((size_t)rp.back());
+      parallel_for(nnode, [&](int64_t b, int64_t e) {
+        for (int64_t n = b; n < e; n++)
+          for (int i = 0; i < nd; i++) {
+            int32_t* out = ci->data() + rp[n * nd + i];
+            for (int64_t k = nb_ptr[n]; k < nb_ptr[n + 1]; k++)
+              for (int j = 0; j < nd; j++) if (off[i][j] >= 0) *out++ = nb[k] * nd + j;
+          }
+      });
+    }
+  };
+
+  std::vector<int64_t> rp; std::vector<int32_t> ci;
+  int cnt[4] = { 0, 0, 0, 0 }, off[4][4] = { { 0 } };
+  bool canonical_dofs = true;
+  if (p->node_dofs) {
+    for (int64_t k = 0; k < nnode * nd && canonical_dofs; k++) canonical_dofs = (p->node_dofs[k] == k);
+  }
+  c->ndof = p->ndof > 0 ? p->ndof : nnode * nd;
+  const int64_t* h_rp = nullptr; const int32_t* h_ci = nullptr;
+  bool rows_ok = canonical_dofs && (c->ndof == nnode * nd);
+  bool col_sorted = true;
+  if (!p->row_ptr) {
+    if (!canonical_dofs || c->ndof != nnode * nd)
+      return fail(FA_ERR_ARG, "a custom dof map needs the caller's CSR pattern (row_ptr/col_idx)");
+    if (p->pattern_kind != FA_PATTERN_FULL && p->pattern_kind != FA_PATTERN_WRITTEN) return fail(FA_ERR_ARG, "invalid pattern_kind");
+    canonical(p->pattern_kind, cnt, off, rp, &ci);
+    h_rp = rp.data(); h_ci = ci.data(); c->own_pattern = true;
+  } else {
+    if (!p->col_idx) return fail(FA_ERR_ARG, "row_ptr given without col_idx");
+    h_rp = p->row_ptr; h_ci = p->col_idx;
+    const int64_t nnz = h_rp[c->ndof];
+    if (rows_ok) {                       // is it one of the canonical blocked layouts?
+      rows_ok = false;
+      for (int kind = 0; kind < 2 && !rows_ok; kind++) {
+        canonical(kind, cnt, off, rp, nullptr);
+        if (rp.back() != nnz || std::memcmp(rp.data(), h_rp, sizeof(int64_t) * rp.size()) != 0) continue;
+        canonical(kind, cnt, off, rp, &ci);
+        rows_ok = std::memcmp(ci.data(), h_ci, sizeof(int32_t) * (size_t)nnz) == 0;
+      }
+    }
+    if (!rows_ok) {
+      for (int64_t r = 0; r < c->ndof && col_sorted; r++)
+        for (int64_t k = h_rp[r] + 1; k < h_rp[r + 1]; k++) if (h_ci[k - 1] >= h_ci[k]) { col_sorted = false; break; }
+    }
+  }
+  c->nnz = h_rp[c->ndof];
+  for (int i = 0; i < 4; i++) { P.cnt[i] = cnt[i]; for (int j = 0; j < 4; j++) P.off[i][j] = off[i][j]; }
+  P.col_sorted = col_sorted;
+
+  // ---- workgroup partition of the node range (row-gather kernel) ----
+  std::vector<int32_t> wg_start;
+  if (rows_ok) {
+    wg_start.push_back(0);
+    int64_t thr = 0, lds = 0, nn = 0;
+    for (int64_t n = 0; n < nnode; n++) {
+      const int64_t v = n2e_ptr[n + 1] - n2e_ptr[n];
+      const int64_t l = h_rp[(n + 1) * nd] - h_rp[n * nd];
+      if (v > fa::kBlock || l > fa::kLdsDoubles) { rows_ok = false; break; }
+      if (thr + v > fa::kBlock || lds + l > fa::kLdsDoubles || nn + 1 > fa::kBlock) {
+        wg_start.push_back((int32_t)n); thr = lds = nn = 0;
+      }
+      thr += v; lds += l; nn++;
+    }
+    wg_start.push_back((int32_t)nnode);
+  }
+  c->rows_path = rows_ok;
+  c->nwg = rows_ok ? (int)wg_start.size() - 1 : 0;
+  c->ngrid_generic = (int)((nel * npe + fa::kBlock - 1) / fa::kBlock);
+
+  // ---- upload ----
+  HIP_TRY(hipSetDevice(p->device));
+  fa_status st;
+  if ((st = upload(&c->d_conn, p->conn, (size_t)nel * npe))) return st;
+  if ((st = upload(&c->d_coords, p->coords, (size_t)nnode * rank))) return st;
+  if ((st = upload(&c->d_row_ptr, h_rp, (size_t)c->ndof + 1))) return st;
+  if ((st = upload(&c->d_col_idx, h_ci, (size_t)c->nnz))) return st;
+  if (!canonical_dofs) { if ((st = upload(&c->d_node_dofs, p->node_dofs, (size_t)nnode * nd))) return st; }
+  if ((st = upload(&c->d_n2e_ptr, n2e_ptr.data(), n2e_ptr.size()))) return st;
+  if ((st = upload(&c->d_n2e_ent, n2e_ent.data(), n2e_ent.size()))) return st;
+  if ((st = upload(&c->d_pos, pos.data(), pos.size()))) return st;
+  if (rows_ok) { if ((st = upload(&c->d_wg_start, wg_start.data(), wg_start.size()))) return st; }
+  {
+    std::vector<double> tab;
+    tab.insert(tab.end(), sh.N.begin(), sh.N.end());
+    tab.insert(tab.end(), sh.dN.begin(), sh.dN.end());
+    tab.insert(tab.end(), sh.w.begin(), sh.w.end());
+    if ((st = upload(&c->d_tab, tab.data(), tab.size()))) return st;
+  }
+  const int64_t nipt = nel * sh.nip;
+  if (p->model == FA_PHASE_FRACTURE) {
+    for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void**)&c->d_hist[k], std::max<int64_t>(nipt, 1) * sizeof(double)));
+    // preHist_.H0_ = Psi0_; newHist_.H0_ = 0 (PhaseFractureModel.cpp:359-360)
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[0], nipt, P.psi0);
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[1], nipt, 0.0);
+  }
+  if (p->model == FA_PHASE_FRACTURE_EXTIT)
+    HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(c->nwg, c->ngrid_generic)));
+  HIP_TRY(hipDeviceSynchronize());
+
+  P.conn = c->d_conn; P.coords = c->d_coords; P.row_ptr = c->d_row_ptr; P.col_idx = c->d_col_idx;
+  P.node_dofs = c->d_node_dofs; P.n2e_ptr = c->d_n2e_ptr; P.n2e_ent = c->d_n2e_ent; P.pos = c->d_pos;
+  P.wg_start = c->d_wg_start; P.tab = c->d_tab; P.max_valence = c->max_valence;
+  return FA_OK;
+}
+
+extern "C" fa_status fa_create(const fa_problem* p, fa_ctx** out) {
+  if (!p || !out) return fail(FA_ERR_ARG, "null argument");
+  *out = nullptr;
+  fa_ctx* c = new fa_ctx();
+  fa_status st = create_impl(p, c);
+  if (st != FA_OK) { std::string keep = g_err; fa_destroy(c); g_err = keep; return st; }
+  *out = c;
+  return FA_OK;
+}
+
+extern "C" int64_t fa_ndof(const fa_ctx* c) { return c->ndof; }
+extern "C" int64_t fa_nnz(const fa_ctx* c) { return c->nnz; }
+extern "C" int64_t fa_nip_total(const fa_ctx* c) { return c->nel * c->nip; }
+extern "C" int32_t fa_ndof_per_node(const fa_ctx* c) { return c->ndofpn; }
+extern "C" int32_t fa_strain_rows(const fa_ctx* c) { return c->srows; }
+extern "C" int32_t fa_uses_row_kernel(const fa_ctx* c) { return c->rows_path ? 1 : 0; }
+extern "C" double  fa_psi0(const fa_ctx* c) { return c->P.psi0; }
+
+extern "C" fa_status fa_pattern_host(const fa_ctx* c, int64_t* row_ptr, int32_t* col_idx) {
+  HIP_TRY(hipSetDevice(c->prob.device));
+  if (row_ptr) HIP_TRY(hipMemcpy(row_ptr, c->d_row_ptr, sizeof(int64_t) * (c->ndof + 1), hipMemcpyDeviceToHost));
+  if (col_idx) HIP_TRY(hipMemcpy(col_idx, c->d_col_idx, sizeof(int32_t) * c->nnz, hipMemcpyDeviceToHost));
+  return FA_OK;
+}
+
+extern "C" fa_status fa_pattern_device(const fa_ctx* c, const int64_t** row_ptr, const int32_t** col_idx) {
+  if (row_ptr) *row_ptr = c->d_row_ptr;
+  if (col_idx) *col_idx = c->d_col_idx;
+  return FA_OK;
+}
+
+extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
+  if (!c || !a) return fail(FA_ERR_ARG, "null argument");
+  if (!a->state || !a->f_int) return fail(FA_ERR_ARG, "state and f_int are required");
+  const int model = c->prob.model;
+  if (model >= FA_PHASE_FRACTURE_EXT && (!a->state0 || !a->state00))
+    return fail(FA_ERR_ARG, "PhaseFractureExt/ExtIt need state0 and state00 (stateExt_)");
+  // LinearElasticityModel answers GET_MATRIX0 only (LinearElasticityModel.cpp:226-246); force-only is still
+  // served here because the kernel supports it.
+  HIP_TRY(hipSetDevice(c->prob.device));
+  hipStream_t st = (hipStream_t)a->stream;
+  fa::Params P = c->P;
+  P.state = a->state; P.state0 = a->state0; P.stateX = a->state00; P.dt = a->dt; P.dt0 = a->dt0;
+  P.K = a->K_values; P.f = a->f_int;
+  P.hist_pre = c->d_hist[0]; P.hist_new = c->d_hist[1];
+  P.overwrite = (a->flags & FA_OVERWRITE) ? 1 : 0;
+  P.strain = nullptr;
+  if (a->flags & FA_STORE_STRAIN) {
+    if (!c->d_strain) HIP_TRY(hipMalloc((void**)&c->d_strain, sizeof(double) * std::max<int64_t>(1, c->nel * c->nip * c->srows)));
+    P.strain = c->d_strain;
+  }
+  const bool want_err = (model == FA_PHASE_FRACTURE_EXTIT) && a->err_ext;
+  P.err_part = want_err ? c->d_err_part : nullptr;
+  const bool want_K = a->K_values != nullptr;
+  const bool keep = want_K && (P.keep2 || P.keep3);
+  const bool rows = c->rows_path && !(a->flags & FA_FORCE_GENERIC);
+  if (c->nel == 0) {
+    if (P.overwrite) {
+      if (want_K) HIP_TRY(hipMemsetAsync(a->K_values, 0, sizeof(double) * c->nnz, st));
+      HIP_TRY(hipMemsetAsync(a->f_int, 0, sizeof(double) * c->ndof, st));
+    }
+    if (want_err) HIP_TRY(hipMemsetAsync(a->err_ext, 0, sizeof(double), st));
+    return FA_OK;
+  }
+  int grid;
+  if (rows) grid = c->nwg;
+  else {
+    grid = c->ngrid_generic;
+    if (P.overwrite) {
+      if (want_K) HIP_TRY(hipMemsetAsync(a->K_values, 0, sizeof(double) * c->nnz, st));
+      HIP_TRY(hipMemsetAsync(a->f_int, 0, sizeof(double) * c->ndof, st));
+    }
+  }
+  int rc = c->launch(P, c->fam, want_K, keep, rows, grid, (void*)st);
+  if (rc == -1000) return fail(FA_ERR_UNSUPPORTED, "kernel family not built for this shape");
+  if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  if (want_err) {
+    hipLaunchKernelGGL(reduce_err_kernel, dim3(1), dim3(256), 0, st, c->d_err_part, grid, a->err_ext);
+    HIP_TRY(hipGetLastError());
+  }
+  return FA_OK;
+}
+
+extern "C" fa_status fa_assemble_host(fa_ctx* c, const double* state, const double* state0, const double* state00,
+                                      double dt, double dt0, double* K, double* f, double* err_ext, int32_t flags) {
+  if (!c || !state || !f) return fail(FA_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(c->prob.device));
+  const size_t nb = sizeof(double) * (size_t)c->ndof;
+  auto stage = [&](double** d, const double* h) -> fa_status {
+    if (!h) return FA_OK;
+    if (!*d) HIP_TRY(hipMalloc((void**)d, nb));
+    HIP_TRY(hipMemcpy(*d, h, nb, hipMemcpyHostToDevice));
+    return FA_OK;
+  };
+  fa_status st;
+  if ((st = stage(&c->s_state, state)) || (st = stage(&c->s_state0, state0)) || (st = stage(&c->s_state00, state00))) return st;
+  if (K && !c->s_K) HIP_TRY(hipMalloc((void**)&c->s_K, sizeof(double) * std::max<int64_t>(1, c->nnz)));
+  if (!c->s_f) HIP_TRY(hipMalloc((void**)&c->s_f, nb));
+  if (!c->s_err) HIP_TRY(hipMalloc((void**)&c->s_err, sizeof(double)));
+  fa_assemble_args a{};
+  a.state = c->s_state; a.state0 = state0 ? c->s_state0 : nullptr; a.state00 = state00 ? c->s_state00 : nullptr;
+  a.dt = dt; a.dt0 = dt0; a.K_values = K ? c->s_K : nullptr; a.f_int = c->s_f;
+  a.err_ext = err_ext ? c->s_err : nullptr;
+  a.flags = (flags & ~FA_ACCUMULATE) | FA_OVERWRITE; a.stream = nullptr;
+  if ((st = fa_assemble(c, &a))) return st;
+  HIP_TRY(hipDeviceSynchronize());
+  const bool over = flags & FA_OVERWRITE;
+  auto fetch = [&](double* h, const double* d, size_t n) -> fa_status {
+    if (over) { HIP_TRY(hipMemcpy(h, d, n * sizeof(double), hipMemcpyDeviceToHost)); return FA_OK; }
+    c->h_tmp.resize(n);
+    HIP_TRY(hipMemcpy(c->h_tmp.data(), d, n * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) h[i] += c->h_tmp[i];
+    return FA_OK;
+  };
+  if (K && (st = fetch(K, c->s_K, (size_t)c->nnz))) return st;
+  if ((st = fetch(f, c->s_f, (size_t)c->ndof))) return st;
+  if (err_ext) {
+    if (c->prob.model == FA_PHASE_FRACTURE_EXTIT) HIP_TRY(hipMemcpy(err_ext, c->s_err, sizeof(double), hipMemcpyDeviceToHost));
+    else *err_ext = 0.0;
+  }
+  return FA_OK;
+}
+
+extern "C" fa_status fa_commit(fa_ctx* c) {
+  if (!c) return fail(FA_ERR_ARG, "null argument");
+  if (c->prob.model == FA_PHASE_FRACTURE) std::swap(c->d_hist[0], c->d_hist[1]);
+  return FA_OK;
+}
+
+extern "C" fa_status fa_get_history(const fa_ctx* c, int32_t which, double* out) {
+  if (!c || !out || which < 0 || which > 1) return fail(FA_ERR_ARG, "bad argument");
+  if (!c->d_hist[which]) return fail(FA_ERR_ARG, "this model keeps no history array");
+  HIP_TRY(hipSetDevice(c->prob.device));
+  HIP_TRY(hipMemcpy(out, c->d_hist[which], sizeof(double) * c->nel * c->nip, hipMemcpyDeviceToHost));
+  return FA_OK;
+}
+
+extern "C" fa_status fa_set_history(fa_ctx* c, int32_t which, const double* in) {
+  if (!c || !in || which < 0 || which > 1) return fail(FA_ERR_ARG, "bad argument");
+  if (!c->d_hist[which]) return fail(FA_ERR_ARG, "this model keeps no history array");
+  HIP_TRY(hipSetDevice(c->prob.device));
+  HIP_TRY(hipMemcpy(c->d_hist[which], in, sizeof(double) * c->nel * c->nip, hipMemcpyHostToDevice));
+  return FA_OK;
+}
+
+extern "C" double* fa_history_device(fa_ctx* c, int32_t which) {
+  return (c && which >= 0 && which <= 1) ? c->d_hist[which] : nullptr;
+}
+
+extern "C" fa_status fa_get_strain_cache(const fa_ctx* c, double* out) {
+  if (!c || !out) return fail(FA_ERR_ARG, "bad argument");
+  if (!c->d_strain) return fail(FA_ERR_ARG, "no call with FA_STORE_STRAIN has been made");
+  HIP_TRY(hipSetDevice(c->prob.device));
+  HIP_TRY(hipMemcpy(out, c->d_strain, sizeof(double) * c->nel * c->nip * c->srows, hipMemcpyDeviceToHost));
+  return FA_OK;
+}

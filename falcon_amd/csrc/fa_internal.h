@@ -1,0 +1,53 @@
+// fa_internal.h -- shared between the host-side C ABI (fa_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+namespace fa {
+
+constexpr int kBlock      = 256;        // threads per workgroup (4 waves of 64)
+constexpr int kLdsDoubles = 6144;       // LDS row buffer capacity per workgroup (48 KiB) -> 3 workgroups / CU
+
+// kernel family: which compute core is instantiated
+enum { FAM_LE = 0, FAM_PF_ISO = 1, FAM_PF_MIEHE = 2 };
+
+struct Params {
+  // ---- mesh / topology (device) ----
+  const int32_t* conn;       // nel*npe
+  const double*  coords;     // nnode*rank
+  const int64_t* row_ptr;    // ndof+1
+  const int32_t* col_idx;    // nnz (generic kernel only)
+  const int64_t* node_dofs;  // nnode*ndofpn or nullptr (generic kernel only)
+  const int32_t* n2e_ptr;    // nnode+1   node -> incident (element, local node) pairs, element-ascending
+  const int32_t* n2e_ent;    // nel*npe   e*npe + la
+  const uint8_t* pos;        // nel*npe*npe: position of node conn[e][lb] in the sorted neighbour list of conn[e][la]
+  const int32_t* wg_start;   // nwg+1     first node of every workgroup
+  const double*  tab;        // shape tables: N[nip][npe], dN[nip][npe][rank], w[nip]
+  // ---- vectors (device) ----
+  const double*  state;
+  const double*  state0;
+  const double*  stateX;     // state00 (Ext) or stateExt_ (ExtIt)
+  const double*  hist_pre;
+  double*        hist_new;
+  double*        strain;     // strain_ cache or nullptr
+  double*        err_part;   // per-workgroup partial sums of (pf-pfEx)^2 (ExtIt) or nullptr
+  double*        K;
+  double*        f;
+  // ---- sizes / switches ----
+  int64_t nnode, nel;
+  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted;
+  int32_t cnt[4];            // entries per neighbour node in a row of dof type i
+  int32_t off[4][4];         // offset of column type j inside that group, -1 if not in the pattern
+  // ---- constants ----
+  double Kb, G, lmda;        // bulk, shear, Miehe's literal lambda
+  double hd0, hd1, hd3;      // Hooke D: normal diagonal, normal off-diagonal, shear
+  double gcl, c2;            // gc/(cw*l0), 2*gc*l0/cw
+  double eta, a1, a2, a3, psi0, beta, dt, dt0;
+};
+
+// launchers, one translation unit per shape (fa_kernels_<shape>.hip)
+typedef int (*launch_fn)(const Params& P, int fam, bool want_K, bool keep, bool rows, int grid, void* stream);
+int launch_tri3_g1 (const Params&, int, bool, bool, bool, int, void*);
+int launch_quad4_g2(const Params&, int, bool, bool, bool, int, void*);
+int launch_hex8_g2 (const Params&, int, bool, bool, bool, int, void*);
+
+}  // namespace fa

@@ -1,0 +1,8 @@
+// gfx950 kernels instantiated for one shape (one translation unit per shape keeps builds parallel).
+#include "fa_kernel_impl.h"
+
+namespace fa {
+int launch_tri3_g1(const Params& P, int fam, bool want_K, bool keep, bool rows, int grid, void* stream) {
+  return launch_shape<Shape<2,3,1>>(P, fam, want_K, keep, rows, grid, stream);
+}
+}  // namespace fa

@@ -1,0 +1,146 @@
+/*
+ * falcon_assemble.h -- C ABI of libfalcon_assemble.so: MI355X (gfx950) element-level
+ * tangent-stiffness / internal-force assembly, the drop-in for the loop behind falcon's
+ * Model::takeAction(GET_MATRIX0 / GET_INT_VECTOR) handlers.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the
+ * ritukeshbharali/falcon checkout).  Plain pointers and sizes only; no torch / Jive types.
+ * All functions return FA_OK (0) or a negative fa_status; fa_last_error() gives the text
+ * (the Jive shim rethrows it as jem::Error, cf. PhaseFractureModel.cpp:239-246).
+ *
+ * Threading: like the reference (takeAction is only ever called from the solver's thread), a
+ * context must not be used from two threads at once.
+ */
+#ifndef FALCON_ASSEMBLE_H
+#define FALCON_ASSEMBLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fa_ctx fa_ctx;
+typedef int32_t fa_status;
+
+enum { FA_OK = 0, FA_ERR_ARG = -1, FA_ERR_UNSUPPORTED = -2, FA_ERR_HIP = -3, FA_ERR_NOMEM = -4 };
+
+/* shape.type / shape.intScheme of the model's "shape" property (IShapeFactory::newInstance,
+ * PhaseFractureModel.cpp:124-128) */
+enum { FA_TRI3_G1 = 0, FA_TRI3_G3 = 1, FA_QUAD4_G2 = 2, FA_QUAD8_G3 = 3, FA_QUAD8_G2 = 4, FA_TRI6_G3 = 5,
+       FA_HEX8_G2 = 6, FA_HEX20_G3 = 7, FA_HEX20_G2 = 8 };
+
+/* ModelFactory names, src/fem/solidmech/FalconSolidMechModels.cpp:10-22 */
+enum { FA_LINEAR_ELASTICITY = 0, FA_PHASE_FRACTURE = 1, FA_PHASE_FRACTURE_EXT = 2, FA_PHASE_FRACTURE_EXTIT = 3 };
+
+/* material.type, newMaterial, src/materials/Material.cpp:233-244 */
+enum { FA_HOOKE = 0, FA_AMOR_PHASE = 1, FA_BOURDIN_PHASE = 2, FA_MIEHE_PHASE = 3 };
+
+/* material.state, src/materials/HookeMaterial.cpp:92-103 */
+enum { FA_PLANE_STRAIN = 0, FA_PLANE_STRESS = 1 };
+
+/* fractureType, PhaseFractureModel.cpp:67-72 */
+enum { FA_AT1 = 0, FA_AT2 = 1, FA_CZM_LINEAR = 2, FA_CZM_EXPONENTIAL = 3, FA_CZM_CORNELISSEN = 4,
+       FA_CZM_HYPERBOLIC = 5 };
+
+/* canonical CSR pattern built when the caller passes none (stand-in for Jive's "FEM" MatrixBuilder,
+ * SURVEY.md 3.4): FULL = every dof-type pair of every node pair sharing an element; WRITTEN = only the
+ * blocks this model writes. */
+enum { FA_PATTERN_FULL = 0, FA_PATTERN_WRITTEN = 1 };
+
+/* fa_assemble flags */
+enum {
+  FA_ACCUMULATE   = 0,  /* K += , f += : the reference's semantics (addBlock / select(force,dofs) +=,
+                           PhaseFractureModel.cpp:738-749); the caller zeroes beforehand */
+  FA_OVERWRITE    = 1,  /* K = , f = over the whole pattern (== caller's zero-fill followed by +=) */
+  FA_STORE_STRAIN = 2,  /* also materialise the strain_ cache (PhaseFractureModel.cpp:651,678) */
+  FA_FORCE_GENERIC = 4  /* testing: use the generic atomic-scatter kernel even for a canonical pattern */
+};
+
+typedef struct {
+  int32_t shape, model, material, state;      /* enums above                                    */
+  double  young, poisson;                      /* material.young / material.poisson              */
+  int32_t frac_type;                           /* fractureType                                   */
+  double  gc, l0, sigma_t, beta;               /* griffithEnergy, lengthScale, tensileStrength, penalty
+                                                  (defaults 2.7, 0.015, 0, 6500: PhaseFractureModel.cpp:253-263,
+                                                  PhaseFractureExtModel.cpp:247) */
+  int32_t keep_off_diags;                      /* keepOffDiags (PhaseFracture only)              */
+
+  int64_t nnode;  const double*  coords;       /* host, nnode*rank, node-major (nodes_.getSomeCoords)   */
+  int64_t nel;    const int32_t* conn;         /* host, nel*npe, 0-based node indices of the model's
+                                                  element group in group order (elems_.getElemNodes)     */
+  /* CSR pattern as the caller's matrix holds it (SparseMatrix::getRowOffsets/getColumnIndices,
+   * src/solvers/linear/cuDSSSolver.cpp:639-663); NULL => canonical pattern of kind pattern_kind.
+   * DOF numbering is node-major, type-minor: dof = node*ndofpn + type (XDofSpace::addDofs order,
+   * PhaseFractureModel.cpp:159-179), unless node_dofs is given. */
+  const int64_t* row_ptr;  const int32_t* col_idx;
+  const int64_t* node_dofs;                    /* host, nnode*ndofpn global dof index per (node,type), or NULL */
+  int64_t ndof;                                /* total dofs of the matrix (0 => nnode*ndofpn)          */
+  int32_t pattern_kind;
+  int32_t device;                              /* HIP device ordinal                                    */
+} fa_problem;
+
+typedef struct {
+  /* all DEVICE pointers unless noted */
+  const double* state;    /* StateVector::get       (PhaseFractureModel.cpp:406)           */
+  const double* state0;   /* StateVector::getOld    (PhaseFractureExtModel.cpp:389); Ext, ExtIt */
+  const double* state00;  /* StateVector::getOldOld (Ext) or stateExt_ (ExtIt, PhaseFractureExtItModel.cpp:407) */
+  double  dt, dt0;        /* XProps::STEP_SIZE / STEP_SIZE_0 as the model holds them (dt_, dt0_) */
+  double* K_values;       /* nnz, NULL => force only (GET_INT_VECTOR)                       */
+  double* f_int;          /* ndof                                                           */
+  double* err_ext;        /* 1 double, ExtIt: errExt_ = sum (pf-pfEx)^2 (PhaseFractureExtItModel.cpp:693); may be NULL */
+  int32_t flags;          /* FA_ACCUMULATE | FA_OVERWRITE | FA_STORE_STRAIN ...             */
+  void*   stream;         /* hipStream_t, NULL => default stream                            */
+} fa_assemble_args;
+
+/* Replaces the model constructor + configure (PhaseFractureModel.cpp:82-267,279-361): element group,
+ * shape, DOF space, material, fracture constants, history allocation (preHist := Psi0). */
+fa_status fa_create(const fa_problem* p, fa_ctx** out);
+/* Model destructor (PhaseFractureModel.cpp:270-271). */
+void      fa_destroy(fa_ctx* ctx);
+const char* fa_last_error(void);
+
+/* sizes: dofs_->dofCount(), nnz of the pattern, ipCount*ielemCount, shape_->ipointCount() etc. */
+int64_t   fa_ndof(const fa_ctx* ctx);
+int64_t   fa_nnz(const fa_ctx* ctx);
+int64_t   fa_nip_total(const fa_ctx* ctx);
+int32_t   fa_ndof_per_node(const fa_ctx* ctx);
+int32_t   fa_strain_rows(const fa_ctx* ctx);
+/* 1 if the coalesced row-gather kernel is used, 0 if the generic atomic-scatter kernel is */
+int32_t   fa_uses_row_kernel(const fa_ctx* ctx);
+/* Psi0_ (PhaseFractureModel.cpp:296-355) */
+double    fa_psi0(const fa_ctx* ctx);
+
+/* CSR pattern hand-off (what the solver wrappers pull: cuDSSSolver.cpp:639-663).  Host copies
+ * (either pointer may be NULL) and device-resident pointers. */
+fa_status fa_pattern_host(const fa_ctx* ctx, int64_t* row_ptr, int32_t* col_idx);
+fa_status fa_pattern_device(const fa_ctx* ctx, const int64_t** row_ptr, const int32_t** col_idx);
+
+/* getMatrix_(mbuilder|nullptr, force, state[, state0, state00]): GET_MATRIX0 / GET_INT_VECTOR
+ * (LinearElasticityModel.cpp:297-430, PhaseFractureModel.cpp:502-751, PhaseFractureExtModel.cpp:488-774,
+ * PhaseFractureExtItModel.cpp:518-797).  Asynchronous on args->stream.  newHist_ is rewritten on every
+ * call (PhaseFractureModel.cpp:703). */
+fa_status fa_assemble(fa_ctx* ctx, const fa_assemble_args* args);
+
+/* Same with HOST vectors (what a Jive shim holds): H2D state, assemble, D2H K/f, synchronous.
+ * K_values/f_int are accumulated into or overwritten on the host according to flags. */
+fa_status fa_assemble_host(fa_ctx* ctx, const double* state, const double* state0, const double* state00,
+                           double dt, double dt0, double* K_values, double* f_int, double* err_ext,
+                           int32_t flags);
+
+/* Actions::COMMIT: newHist_.H0_.swap(preHist_.H0_) (PhaseFractureModel.cpp:468-473). */
+fa_status fa_commit(fa_ctx* ctx);
+
+/* History (Flex<double> H0_, PhaseFractureModel.h:292-298): which = 0 preHist_, 1 newHist_.  Host copies
+ * (checkpoint / restart) and the device pointer. */
+fa_status fa_get_history(const fa_ctx* ctx, int32_t which, double* host_out);
+fa_status fa_set_history(fa_ctx* ctx, int32_t which, const double* host_in);
+double*   fa_history_device(fa_ctx* ctx, int32_t which);
+/* strain_ cache, (str[+1]) x nip_total, column = ipoint (PhaseFractureModel.cpp:187); filled by calls
+ * made with FA_STORE_STRAIN. */
+fa_status fa_get_strain_cache(const fa_ctx* ctx, double* host_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,215 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): CSR pattern / DOF indexing bit-exact, K and f_int within 1e-12
+relative (per-row max scale, SURVEY.md gotcha 14)."""
+import numpy as np
+import pytest
+
+from falcon_amd import capi, meshgen
+from oracle import pyoracle as po
+from tests.conftest import rel_rowmax_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+MESH = {capi.TRI3_G1: lambda: meshgen.grid_tri3(9, 7), capi.QUAD4_G2: lambda: meshgen.grid_quad4(11, 9),
+        capi.HEX8_G2: lambda: meshgen.grid_hex8(5, 4, 3)}
+
+
+def vec_err(got, ref):
+    return np.abs(got - ref).max() / np.abs(ref).max()
+
+
+def make_case(shape, model, material, keep=0, frac=capi.AT2, state2d=capi.PLANE_STRAIN, shuffle=False, seed=1,
+              sigma_t=0.0, young=210.0, gc=2.7e-3, l0=0.2):
+    coords, conn = MESH[shape]()
+    coords = meshgen.distort(coords, conn, 0.15, seed)
+    if shuffle:
+        coords, conn, _ = meshgen.shuffle_nodes(coords, conn, seed)
+    rank = coords.shape[1]
+    nd = rank + (0 if model == capi.LINEAR_ELASTICITY else 1)
+    st = meshgen.smooth_state(coords, nd, seed=seed, amp=5e-3, noise=1e-4, l0=0.3)
+    kw = dict(state=state2d, young=young, poisson=0.3, frac_type=frac, gc=gc, l0=l0, sigma_t=sigma_t, beta=6500.0,
+              keep_off_diags=keep)
+    cfg = po.make_config(shape, model, material, **kw)
+    return coords, conn, st, kw, cfg
+
+
+def run_both(shape, model, material, *, keep=0, kind=capi.PATTERN_FULL, flags=capi.OVERWRITE, want_K=True, **kws):
+    import torch
+    coords, conn, st, kw, cfg = make_case(shape, model, material, keep, **kws)
+    asm = capi.Assembler(shape, model, material, coords, conn, pattern_kind=kind, **kw)
+    rank = coords.shape[1]
+    rp, ci = asm.pattern()
+    rpo, cio = po.pattern(coords.shape[0], conn, asm.ndofpn, rank, kind, po.keep_code(cfg))
+    assert np.array_equal(rp, rpo) and np.array_equal(ci, cio)            # bit-exact pattern / dof indexing
+    rng = np.random.default_rng(7)
+    nip_t = conn.shape[0] * asm.nip
+    H0 = rng.uniform(0, 2e-3, nip_t)
+    st0 = st.copy(); st00 = st.copy()
+    if asm.ndofpn > rank:
+        st0[rank::asm.ndofpn] += rng.uniform(-0.02, 0.02, coords.shape[0])
+        st00[rank::asm.ndofpn] += rng.uniform(-0.02, 0.02, coords.shape[0])
+    dev = torch.device("cuda", 0)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    K0 = rng.uniform(-1, 1, asm.nnz); f0 = rng.uniform(-1, 1, asm.ndof)
+    K = d(K0) if want_K else None
+    f = d(f0)
+    err = torch.zeros(1, dtype=torch.float64, device=dev)
+    if model == capi.PHASE_FRACTURE:
+        asm.set_history(0, H0)
+    ext = model >= capi.PHASE_FRACTURE_EXT
+    asm.assemble(d(st), K, f, state0=d(st0) if ext else None, state00=d(st00) if ext else None, dt=0.7, dt0=0.4,
+                 err_ext=err, flags=flags | capi.STORE_STRAIN)
+    torch.cuda.synchronize()
+    ref = po.assemble(cfg, coords, conn, rpo, cio, st, state0=st0 if ext else None, state00=st00 if ext else None,
+                      dt=0.7, dt0=0.4, hist_pre=H0 if model == capi.PHASE_FRACTURE else None, want_K=want_K,
+                      want_strain=True)
+    over = bool(flags & capi.OVERWRITE)
+    if want_K:
+        got = K.cpu().numpy() - (0 if over else K0)
+        assert rel_rowmax_err(rp, got, ref["K"]) < (TOL if over else 1e-10)
+    gotf = f.cpu().numpy() - (0 if over else f0)
+    assert vec_err(gotf, ref["f"]) < (TOL if over else 1e-10)
+    if model == capi.PHASE_FRACTURE:
+        assert vec_err(asm.get_history(1), ref["hist_new"]) < TOL
+        assert np.array_equal(asm.get_history(0), H0)
+    if model == capi.PHASE_FRACTURE_EXTIT:
+        assert abs(err.item() - ref["err_ext"]) < 1e-12 * ref["err_ext"]
+    sc = asm.get_strain_cache()
+    assert np.abs(sc - ref["strain"]).max() < TOL * np.abs(ref["strain"]).max()
+    return asm
+
+
+@pytest.mark.parametrize("shape", [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2])
+@pytest.mark.parametrize("state2d", [capi.PLANE_STRAIN, capi.PLANE_STRESS])
+def test_linear_elasticity(shape, state2d):
+    asm = run_both(shape, capi.LINEAR_ELASTICITY, capi.HOOKE, state2d=state2d)
+    assert asm.uses_row_kernel
+
+
+@pytest.mark.parametrize("shape", [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2])
+@pytest.mark.parametrize("material", [capi.AMOR_PHASE, capi.BOURDIN_PHASE])
+@pytest.mark.parametrize("keep", [0, 1])
+def test_phase_fracture(shape, material, keep):
+    run_both(shape, capi.PHASE_FRACTURE, material, keep=keep)
+
+
+@pytest.mark.parametrize("shape", [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2])
+@pytest.mark.parametrize("model", [capi.PHASE_FRACTURE_EXT, capi.PHASE_FRACTURE_EXTIT])
+def test_phase_fracture_ext(shape, model):
+    run_both(shape, model, capi.AMOR_PHASE)
+
+
+@pytest.mark.parametrize("frac", [capi.AT1, capi.CZM_LINEAR, capi.CZM_EXPONENTIAL, capi.CZM_CORNELISSEN,
+                                  capi.CZM_HYPERBOLIC])
+def test_fracture_laws(frac):
+    run_both(capi.QUAD4_G2, capi.PHASE_FRACTURE, capi.AMOR_PHASE, keep=1, frac=frac, sigma_t=3.0, young=3e4,
+             gc=0.12, l0=0.25)
+
+
+@pytest.mark.parametrize("shape", [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2])
+def test_written_pattern_accumulate_shuffled(shape):
+    run_both(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, keep=0, kind=capi.PATTERN_WRITTEN, flags=capi.ACCUMULATE,
+             shuffle=True)
+    run_both(shape, capi.PHASE_FRACTURE_EXT, capi.BOURDIN_PHASE, kind=capi.PATTERN_WRITTEN, shuffle=True)
+
+
+@pytest.mark.parametrize("shape", [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2])
+def test_force_only(shape):
+    run_both(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, want_K=False)
+    run_both(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, want_K=False, flags=capi.ACCUMULATE)
+
+
+@pytest.mark.parametrize("shape", [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2])
+@pytest.mark.parametrize("flags", [capi.OVERWRITE, capi.ACCUMULATE])
+def test_generic_kernel_on_canonical_pattern(shape, flags):
+    run_both(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, keep=1, flags=flags | capi.FORCE_GENERIC)
+
+
+def test_generic_kernel_custom_dofs_and_unsorted_pattern():
+    """A caller-supplied (Jive-like) dof numbering and a CSR whose rows are not column-sorted."""
+    import torch
+    shape, model, material = capi.QUAD4_G2, capi.PHASE_FRACTURE, capi.AMOR_PHASE
+    coords, conn, st, kw, cfg = make_case(shape, model, material, 1)
+    nn = coords.shape[0]; nd = 3
+    rp, ci = po.pattern(nn, conn, nd, 2)
+    ref = po.assemble(cfg, coords, conn, rp, ci, st)
+    rng = np.random.default_rng(11)
+    perm = rng.permutation(nn * nd)                  # canonical dof k -> caller's dof perm[k]
+    ndof = nn * nd
+    # caller's CSR: row perm[r] holds columns perm[ci] in shuffled order
+    inv = np.empty(ndof, dtype=np.int64); inv[perm] = np.arange(ndof)
+    lens = np.diff(rp)
+    rp2 = np.zeros(ndof + 1, dtype=np.int64); rp2[1:] = np.cumsum(lens[inv])
+    ci2 = np.empty_like(ci); src = np.empty(ci.size, dtype=np.int64)
+    for r2 in range(ndof):
+        r = inv[r2]
+        idx = np.arange(rp[r], rp[r + 1]); rng.shuffle(idx)
+        ci2[rp2[r2]:rp2[r2 + 1]] = perm[ci[idx]]; src[rp2[r2]:rp2[r2 + 1]] = idx
+    asm = capi.Assembler(shape, model, material, coords, conn, row_ptr=rp2, col_idx=ci2,
+                         node_dofs=perm.astype(np.int64), ndof=ndof, **kw)
+    assert not asm.uses_row_kernel
+    st2 = np.empty_like(st); st2[perm] = st
+    K, f, _ = asm.assemble_host(st2, np.zeros(asm.nnz), flags=capi.OVERWRITE)
+    assert rel_rowmax_err(rp2, K, ref["K"][src]) < TOL
+    assert vec_err(f[perm], ref["f"]) < TOL
+
+
+def test_history_commit_cycle_and_host_path():
+    """COMMIT swaps newHist_/preHist_ (PhaseFractureModel.cpp:468-473); a second load step sees the first
+    step's Psi as H0; loading flag only matters for K3."""
+    shape, model, material = capi.QUAD4_G2, capi.PHASE_FRACTURE, capi.BOURDIN_PHASE
+    coords, conn, st, kw, cfg = make_case(shape, model, material, 1)
+    asm = capi.Assembler(shape, model, material, coords, conn, **kw)
+    rp, ci = asm.pattern()
+    K1, f1, _ = asm.assemble_host(st, np.zeros(asm.nnz), flags=capi.OVERWRITE)
+    r1 = po.assemble(cfg, coords, conn, rp, ci, st)
+    assert rel_rowmax_err(rp, K1, r1["K"]) < TOL
+    asm.commit()
+    assert vec_err(asm.get_history(0), r1["hist_new"]) < TOL
+    st2 = st.copy(); st2[0::3] *= 0.5; st2[1::3] *= 1.5          # part unloads, part loads further
+    K2 = np.ones(asm.nnz); f2 = np.ones(asm.ndof)
+    asm.assemble_host(st2, K2, f2, flags=capi.ACCUMULATE)
+    r2 = po.assemble(cfg, coords, conn, rp, ci, st2, hist_pre=r1["hist_new"])
+    assert rel_rowmax_err(rp, K2 - 1.0, r2["K"]) < 1e-10
+    assert vec_err(f2 - 1.0, r2["f"]) < 1e-10
+    assert vec_err(asm.get_history(1), r2["hist_new"]) < TOL
+    # force-only call rewrites newHist_ too (gotcha 9)
+    asm.set_history(1, np.zeros(asm.nip_total))
+    asm.assemble_host(st2, None, np.zeros(asm.ndof), flags=capi.OVERWRITE)
+    assert vec_err(asm.get_history(1), r2["hist_new"]) < TOL
+
+
+def test_sm01_as_shipped():
+    """Config 1: tests/sm01 (2 Triangle3, Hooke plane stress) -- closed form of SURVEY.md 8c KAT-1."""
+    coords = np.array([[0., 0.], [1., 0.], [1., 1.], [0., 1.]])
+    conn = np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int32)
+    asm = capi.Assembler(capi.TRI3_G1, capi.LINEAR_ELASTICITY, capi.HOOKE, coords, conn, state=capi.PLANE_STRESS,
+                         young=1e4, poisson=0.3)
+    assert asm.nnz == 56
+    u = np.zeros(8); u[5] = u[7] = 1e-4
+    K, f, _ = asm.assemble_host(u, np.zeros(56), flags=capi.OVERWRITE)
+    rp, ci = asm.pattern()
+    a = 1e4 / (1 - 0.09); G = a * 0.35
+    row0 = dict(zip(ci[rp[0]:rp[1]], K[rp[0]:rp[1]]))
+    exp = {0: (a + G) / 2, 1: 0, 2: -a / 2, 3: a * 0.3 / 2, 4: 0, 5: -(a * 0.3 + G) / 2, 6: -G / 2, 7: G / 2}
+    for c, v in exp.items():
+        assert abs(row0[c] - v) < 1e-12 * a
+    assert abs(f[5] + f[7] - 1.0989010989010989) < 1e-13
+
+
+def test_empty_and_single_element():
+    coords = np.array([[0., 0.], [2., 0.], [0., 1.]])
+    conn = np.array([[0, 1, 2]], dtype=np.int32)
+    asm = capi.Assembler(capi.TRI3_G1, capi.LINEAR_ELASTICITY, capi.HOOKE, coords, conn, young=10.0)
+    cfg = po.make_config(po.TRI3_G1, po.LINEAR_ELASTICITY, po.HOOKE, young=10.0)
+    rp, ci = asm.pattern()
+    u = np.arange(6) * 1e-3
+    K, f, _ = asm.assemble_host(u, np.zeros(asm.nnz), flags=capi.OVERWRITE)
+    ref = po.assemble(cfg, coords, conn, rp, ci, u)
+    assert rel_rowmax_err(rp, K, ref["K"]) < TOL
+    asm0 = capi.Assembler(capi.TRI3_G1, capi.LINEAR_ELASTICITY, capi.HOOKE, coords, np.zeros((0, 3), np.int32))
+    assert asm0.nnz == 0
+    K, f, _ = asm0.assemble_host(u, np.zeros(0), np.ones(6), flags=capi.OVERWRITE)
+    assert np.all(f == 0)
