@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- assembled elements/s (K + f_int) of the MI355X assembly path, BASELINE.json metric.
+
+A "step" is one GET_MATRIX0 pass (tangent stiffness K into the CSR value array + internal force f_int)
+over the whole synthetic mesh, inputs resident in HBM.  N=1 workload = BASELINE.json configs[2]
+("cfg3": 4000x4000 Q4, coupled u-phi phase-field fracture, AT2, AmorPhase).  N>1: weak
+scaling, one 4000x(4000) strip per GPU stacked in y, interface f_int entries summed with the
+neighbouring ranks over RCCL (falcon_amd/distributed.py); value = all ranks' elements / max time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4] [--n SIZE]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def algorithmic_bytes(nnz_written, ndof, nnode, rank, npe, nel, nip, phase_field):
+    """every input read once, every output written once."""
+    b = 8 * nnz_written + 8 * ndof + 8 * ndof + 8 * rank * nnode + 4 * npe * nel
+    if phase_field:
+        b += 16 * nip * nel
+    return b
+
+
+def workload(name, n, capi):
+    if name == "cfg2":
+        n = n or 1000
+        return dict(desc=f"cfg2: {n}x{n} Q4 linear-elastic plate (Hooke, plane strain)", shape=capi.QUAD4_G2,
+                    model=capi.LINEAR_ELASTICITY, material=capi.HOOKE, dims=(n, n), h=1.0 / n,
+                    written_per_pair=4, kw=dict(young=210e3, poisson=0.3))
+    if name == "cfg3":
+        n = n or 4000
+        return dict(desc=f"cfg3: {n}x{n} Q4 single-edge-notched tension, phase-field fracture (u-phi), AT2, AmorPhase, "
+                         "keepOffDiags=false", shape=capi.QUAD4_G2, model=capi.PHASE_FRACTURE,
+                    material=capi.AMOR_PHASE, dims=(n, n), h=1.0 / n, written_per_pair=5,
+                    kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=False))
+    if name == "cfg4":
+        n = n or 200
+        return dict(desc=f"cfg4: {n}^3 hex8 phase-field fracture cube, AT2, AmorPhase", shape=capi.HEX8_G2,
+                    model=capi.PHASE_FRACTURE, material=capi.AMOR_PHASE, dims=(n, n, n), h=1.0 / n,
+                    written_per_pair=10, kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2))
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(wl, capi, meshgen, target_elems):
+    """The CPU restatement (oracle) of the reference loop, 1 core, on a bounded sample of the same workload."""
+    from oracle import pyoracle as po
+    rank = len(wl["dims"])
+    if rank == 2:
+        m = max(8, int(round(target_elems ** 0.5)))
+        coords, conn = meshgen.grid_quad4(m, m, m * wl["h"], m * wl["h"])
+        sample = f"{m}x{m} Q4 sub-grid of the same mesh (same h, material, state field), one K+f_int pass"
+    else:
+        m = max(4, int(round(target_elems ** (1.0 / 3.0))))
+        coords, conn = meshgen.grid_hex8(m, m, m, m * wl["h"], m * wl["h"], m * wl["h"])
+        sample = f"{m}^3 hex8 sub-grid of the same mesh, one K+f_int pass"
+    kw = dict(wl["kw"])
+    cfg = po.make_config(wl["shape"], wl["model"], wl["material"], young=kw["young"], poisson=kw["poisson"],
+                         gc=kw.get("gc", 2.7), l0=kw.get("l0", 0.015), frac_type=kw.get("frac_type", 1),
+                         keep_off_diags=int(kw.get("keep_off_diags", False)))
+    nd = po.ndof_per_node(wl["model"], rank)
+    rp, ci = po.pattern(coords.shape[0], conn, nd, rank)
+    st = meshgen.smooth_state(coords, nd)
+    t = time.perf_counter()
+    po.assemble(cfg, coords, conn, rp, ci, st)
+    dt = time.perf_counter() - t
+    return dict(value=conn.shape[0] / dt, unit="elements/s", cores=1, kind="port", sample=sample,
+                seconds=round(dt, 2))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--n", type=int, default=0, help="elements per side (default: the BASELINE size)")
+    ap.add_argument("--mode", default="overwrite", choices=["overwrite", "accumulate"])
+    ap.add_argument("--pattern", default="full", choices=["full", "written"])
+    ap.add_argument("--force-only", action="store_true", help="GET_INT_VECTOR pass instead of GET_MATRIX0")
+    ap.add_argument("--cpu-elems", type=int, default=2250000, help="elements in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from falcon_amd import capi, meshgen
+    from falcon_amd.distributed import StripPartition, halo_sum
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = workload(args.workload, args.n, capi)
+    rk = len(wl["dims"])
+    t_setup = time.perf_counter()
+    part = None
+    if rk == 2:
+        nx, ny = wl["dims"]
+        if world > 1:      # weak scaling: every rank gets a full-size strip, stacked in y
+            part = StripPartition(nx, ny * world, world, rank, 3 if wl["model"] else 2)
+            coords, conn = part.local_mesh(meshgen, wl["h"])
+        else:
+            coords, conn = meshgen.grid_quad4(nx, ny, nx * wl["h"], ny * wl["h"])
+    else:
+        nx, ny, nz = wl["dims"]
+        coords, conn = meshgen.grid_hex8(nx, ny, nz, nx * wl["h"], ny * wl["h"], nz * wl["h"])
+        if world > 1:
+            raise SystemExit("multi-GPU bench is implemented for the 2D strip partition")
+    kind = capi.PATTERN_FULL if args.pattern == "full" else capi.PATTERN_WRITTEN
+    asm = capi.Assembler(wl["shape"], wl["model"], wl["material"], coords, conn, pattern_kind=kind,
+                         device=local_rank, **wl["kw"])
+    assert asm.uses_row_kernel
+    state = torch.from_numpy(meshgen.smooth_state(coords, asm.ndofpn, seed=12345 + rank)).to(dev)
+    del coords
+    want_K = not args.force_only
+    K = torch.zeros(asm.nnz, dtype=torch.float64, device=dev) if want_K else None
+    f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+    flags = capi.OVERWRITE if args.mode == "overwrite" else capi.ACCUMULATE
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    def step():
+        asm.assemble(state, K, f, flags=flags)
+        if part is not None:
+            halo_sum(f, part)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        asm.assemble(state, K, f, flags=flags)
+        ev[i][1].record()
+        if part is not None:
+            halo_sum(f, part)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+        nel_total = torch.tensor([asm.nel], dtype=torch.float64, device=dev)
+        dist.all_reduce(nel_total)
+        nel_total = nel_total.item()
+    else:
+        nel_total = asm.nel
+
+    if rank == 0:
+        pf = wl["model"] != capi.LINEAR_ELASTICITY
+        pairs = asm.nnz // (asm.ndofpn ** 2 if kind == capi.PATTERN_FULL else wl["written_per_pair"])
+        nnz_written = pairs * wl["written_per_pair"] if want_K else 0
+        ab = algorithmic_bytes(nnz_written, asm.ndof, asm.nnode, asm.rank, asm.npe, asm.nel, asm.nip, pf)
+        achieved = ab / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            key = f"{args.workload}:{asm.nel}:{args.mode}:{args.pattern}:{'f' if args.force_only else 'K'}"
+            traffic = json.load(open(tf)).get(key)
+        out = {
+            "metric": "assembled elements/sec (K + f_int)" if want_K else "assembled elements/sec (f_int only)",
+            "value": nel_total * args.steps / elapsed, "unit": "elements/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl["desc"], "elements_per_gpu": asm.nel, "ndof_per_gpu": asm.ndof,
+                       "nnz_per_gpu": asm.nnz, "mode": args.mode, "pattern": args.pattern,
+                       "partition": "y-strips, f_int interface halo-sum over RCCL" if world > 1 else "single GPU",
+                       "setup_seconds": round(t_setup, 2)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic, "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": ab, "bytes_per_element": ab / asm.nel},
+        }
+        if world == 1 and args.cpu_elems > 0:
+            out["cpu_baseline"] = cpu_baseline(wl, capi, meshgen, args.cpu_elems)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
