@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfalcon_assemble.so")
+LIB_PATH = os.environ.get("FA_LIB") or os.path.join(_HERE, "libfalcon_assemble.so")
 
 # enums of include/falcon_assemble.h
 TRI3_G1, TRI3_G3, QUAD4_G2, QUAD8_G3, QUAD8_G2, TRI6_G3, HEX8_G2, HEX20_G3, HEX20_G2 = range(9)

@@ -147,7 +147,7 @@ struct fa_ctx {
   int rank = 0, npe = 0, nip = 0, str = 0, ndofpn = 0, fam = 0, srows = 0;
   int64_t nnode = 0, nel = 0, ndof = 0, nnz = 0;
   bool rows_path = false, own_pattern = false;
-  int nwg = 0, max_valence = 0, ngrid_generic = 0;
+  int nwg = 0, max_valence = 0, ngrid_generic = 0, block = 0;
   fa::launch_fn launch = nullptr;
   fa::Params P{};
   // device
@@ -165,11 +165,11 @@ extern "C" const char* fa_last_error(void) { return g_err.c_str(); }
 
 extern "C" void fa_destroy(fa_ctx* c) {
   if (!c) return;
-  hipSetDevice(c->prob.device);
+  (void)hipSetDevice(c->prob.device);
   void* ptrs[] = { c->d_conn, c->d_coords, c->d_row_ptr, c->d_col_idx, c->d_node_dofs, c->d_n2e_ptr, c->d_n2e_ent,
                    c->d_pos, c->d_wg_start, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part,
                    c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err };
-  for (void* p : ptrs) if (p) hipFree(p);
+  for (void* p : ptrs) if (p) (void)hipFree(p);
   delete c;
 }
 
@@ -365,14 +365,16 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
 
   // ---- workgroup partition of the node range (row-gather kernel) ----
   std::vector<int32_t> wg_start;
+  const int kBlock = fa::block_for(rank), kLds = fa::lds_for(rank);
+  c->block = kBlock;
   if (rows_ok) {
     wg_start.push_back(0);
     int64_t thr = 0, lds = 0, nn = 0;
     for (int64_t n = 0; n < nnode; n++) {
       const int64_t v = n2e_ptr[n + 1] - n2e_ptr[n];
       const int64_t l = h_rp[(n + 1) * nd] - h_rp[n * nd];
-      if (v > fa::kBlock || l > fa::kLdsDoubles) { rows_ok = false; break; }
-      if (thr + v > fa::kBlock || lds + l > fa::kLdsDoubles || nn + 1 > fa::kBlock) {
+      if (v > kBlock || l > kLds) { rows_ok = false; break; }
+      if (thr + v > kBlock || lds + l > kLds || nn + 1 > kBlock) {
         wg_start.push_back((int32_t)n); thr = lds = nn = 0;
       }
       thr += v; lds += l; nn++;
@@ -381,7 +383,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   }
   c->rows_path = rows_ok;
   c->nwg = rows_ok ? (int)wg_start.size() - 1 : 0;
-  c->ngrid_generic = (int)((nel * npe + fa::kBlock - 1) / fa::kBlock);
+  c->ngrid_generic = (int)((nel * npe + kBlock - 1) / kBlock);
 
   // ---- upload ----
   HIP_TRY(hipSetDevice(p->device));

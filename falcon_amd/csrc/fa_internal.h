@@ -4,8 +4,19 @@
 
 namespace fa {
 
-constexpr int kBlock      = 256;        // threads per workgroup (4 waves of 64)
-constexpr int kLdsDoubles = 6144;       // LDS row buffer capacity per workgroup (48 KiB) -> 3 workgroups / CU
+// Workgroup geometry per space dimension: threads per workgroup and capacity (in doubles) of the LDS image
+// of the CSR rows.  2D: 128 threads + 20 KiB => 7-8 workgroups per CU; 3D row blocks are ~5x larger.
+#ifndef FA_BLOCK2D
+#define FA_BLOCK2D 256
+#endif
+#ifndef FA_LDS2D
+#define FA_LDS2D 5120
+#endif
+#ifndef FA_WAVES2D
+#define FA_WAVES2D 1
+#endif
+constexpr int block_for(int rank) { return rank == 2 ? FA_BLOCK2D : 256; }
+constexpr int lds_for(int rank)   { return rank == 2 ? FA_LDS2D : 12288; }
 
 // kernel family: which compute core is instantiated
 enum { FAM_LE = 0, FAM_PF_ISO = 1, FAM_PF_MIEHE = 2 };

@@ -27,6 +27,8 @@ struct Shape {
   static constexpr int S   = (RANK_ == 2) ? 3 : 6;   // strain components that matter (2D: xx, yy, xy)
   static constexpr int STR = (RANK_ == 2) ? 4 : 6;   // STRAIN_COUNTS (util/Constants.cpp:9)
   static constexpr int ND  = RANK_ * NPE_;
+  static constexpr int BLOCK = block_for(RANK_), LDS = lds_for(RANK_);
+  static constexpr int MIN_WAVES = (RANK_ == 2) ? FA_WAVES2D : 1;   // waves per SIMD the register allocator must allow
 };
 
 template <class SH, bool WANT_K, bool PF, bool KEEP>
@@ -131,6 +133,14 @@ __device__ __forceinline__ void Bt_vec(const double (&ga)[RANK], const double (&
 template <class SH, int FAM, bool WANT_K, bool KEEP>
 __device__ __forceinline__ void compute_rowblock(const Params& P, int64_t e, int la, const int32_t (&cn)[SH::NPE],
                                                  RowBlock<SH, WANT_K, FAM != FAM_LE, KEEP>& R, double& err_acc) {
+  // preHist_.H0_ of all Gauss points of e: one contiguous read, issued with the other gathers
+  double H0v[SH::NIP];
+  if constexpr (FAM != FAM_LE) {
+    if (P.model == 1) {
+#pragma unroll
+      for (int ip = 0; ip < SH::NIP; ip++) H0v[ip] = P.hist_pre[e * SH::NIP + ip];
+    }
+  }
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, S = SH::S, STR = SH::STR;
   constexpr bool PF = (FAM != FAM_LE);
   const int ndofpn = PF ? RANK + 1 : RANK;
@@ -295,7 +305,7 @@ __device__ __forceinline__ void compute_rowblock(const Params& P, int64_t e, int
       if (P.strain != nullptr && owner) P.strain[ipoint * srows + STR] = gmat;
       iso_update<RANK, S>(P, eps, gmat, d0, d1, d3, sig, sp, Psi);
       if (P.model == 1) {
-        const double H0 = P.hist_pre[ipoint];           // PhaseFractureModel.cpp:696-703
+        const double H0 = H0v[ip];                      // PhaseFractureModel.cpp:696-703
         if (Psi < H0) loading = 0.0;
         Psi = (Psi > H0) ? Psi : H0;
         if (owner) P.hist_new[ipoint] = Psi;
@@ -392,8 +402,8 @@ __device__ __forceinline__ void compute_rowblock(const Params& P, int64_t e, int
 // Row-gather kernel (canonical node-major dofs, column-sorted blocked pattern)
 // ------------------------------------------------------------------------------------------------
 template <class SH, int FAM, bool WANT_K, bool KEEP>
-__global__ __launch_bounds__(kBlock) void assemble_rows(const Params P) {
-  constexpr int RANK = SH::RANK, NPE = SH::NPE;
+__global__ __launch_bounds__(SH::BLOCK, SH::MIN_WAVES) void assemble_rows(const Params P) {
+  constexpr int RANK = SH::RANK, NPE = SH::NPE, kBlock = SH::BLOCK, kLdsDoubles = SH::LDS;
   constexpr bool PF = (FAM != FAM_LE);
   constexpr int NDOF = PF ? RANK + 1 : RANK;
   __shared__ double sK[WANT_K ? kLdsDoubles : 1];
@@ -416,6 +426,8 @@ __global__ __launch_bounds__(kBlock) void assemble_rows(const Params P) {
   int32_t cn[NPE];
   int la = 0, slot = -1, a = n0;
   int64_t e = 0;
+  int rs[NDOF];
+  uint8_t ps[NPE];
   double err_acc = 0.0;
   if (active) {
     const int ent = P.n2e_ent[t];
@@ -425,27 +437,53 @@ __global__ __launch_bounds__(kBlock) void assemble_rows(const Params P) {
 #pragma unroll
     for (int b = 0; b < NPE; b++) if (b == la) a = cn[b];
     slot = t - P.n2e_ptr[a];
-    compute_rowblock<SH, FAM, WANT_K, KEEP>(P, e, la, cn, R, err_acc);
-  }
-  __syncthreads();
-
-  // ---- phased, conflict-free accumulation into the LDS image of the CSR rows ----
-  int rs[NDOF];
-  uint8_t ps[NPE];
-  if (active) {
-    if constexpr (WANT_K) {
+    if constexpr (WANT_K) {                        // row starts / column positions: issued before the compute
 #pragma unroll
       for (int i = 0; i < NDOF; i++) rs[i] = (int)(P.row_ptr[(int64_t)a * NDOF + i] - base);
 #pragma unroll
       for (int b = 0; b < NPE; b++) ps[b] = P.pos[(e * NPE + la) * NPE + b];
     }
+#if defined(FA_ABLATE) && (FA_ABLATE & 2)
+    {   // experiment: gathers only, no Gauss-point arithmetic
+      double acc = 0.0;
+      for (int b = 0; b < NPE; b++) { acc += P.coords[(int64_t)cn[b] * RANK] + P.coords[(int64_t)cn[b] * RANK + 1];
+        for (int i = 0; i < NDOF; i++) acc += P.state[(int64_t)cn[b] * NDOF + i]; }
+      for (int ip = 0; ip < SH::NIP; ip++) acc += P.hist_pre[e * SH::NIP + ip];
+      for (int i = 0; i < RANK; i++) R.fu[i] = acc; R.fp = acc;
+      if constexpr (WANT_K) { for (int i = 0; i < RANK; i++) for (int j = 0; j < SH::ND; j++) R.Kuu[i][j] = acc + j;
+        if constexpr (PF) for (int b = 0; b < NPE; b++) R.Kpp[b] = acc - b; }
+    }
+#else
+    compute_rowblock<SH, FAM, WANT_K, KEEP>(P, e, la, cn, R, err_acc);
+#endif
   }
+  __syncthreads();
+
+  // ---- phased, conflict-free accumulation into the LDS image of the CSR rows ----
+#ifdef FA_LDS_ATOMIC
+#define FA_LDS_ADD(ref, v) __hip_atomic_fetch_add(&(ref), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#else
+#define FA_LDS_ADD(ref, v) (ref) += (v)
+#endif
+#if defined(FA_ABLATE) && (FA_ABLATE & 4)
+  if (active) { asm volatile("" :: "v"(R.fu[0]), "v"(R.fp)); if constexpr (WANT_K) { for (int j = 0; j < SH::ND; j++) asm volatile("" :: "v"(R.Kuu[0][j]), "v"(R.Kuu[1][j])); if constexpr (PF) for (int b = 0; b < NPE; b++) asm volatile("" :: "v"(R.Kpp[b])); } }
+  for (int s = 0; s < 0; s++) {
+#else
+#ifdef FA_LDS_ATOMIC
+  for (int s = 0; s < 1; s++) {
+#else
   for (int s = 0; s < P.max_valence; s++) {
+#endif
+#endif
+#ifdef FA_LDS_ATOMIC
+    if (active) {
+#else
     if (active && slot == s) {
+#endif
       const int fo = (a - n0) * NDOF;
 #pragma unroll
-      for (int i = 0; i < RANK; i++) sF[fo + i] += R.fu[i];
-      if constexpr (PF) sF[fo + RANK] += R.fp;
+      for (int i = 0; i < RANK; i++) FA_LDS_ADD(sF[fo + i], R.fu[i]);
+      if constexpr (PF) FA_LDS_ADD(sF[fo + RANK], R.fp);
       if constexpr (WANT_K) {
 #pragma unroll
         for (int i = 0; i < RANK; i++) {
@@ -453,19 +491,19 @@ __global__ __launch_bounds__(kBlock) void assemble_rows(const Params P) {
           for (int b = 0; b < NPE; b++) {
             const int gs = rs[i] + (int)ps[b] * P.cnt[i];
 #pragma unroll
-            for (int j = 0; j < RANK; j++) sK[gs + P.off[i][j]] += R.Kuu[i][b * RANK + j];
-            if constexpr (KEEP) { if (P.keep2) sK[gs + P.off[i][RANK]] += R.Kup[i][b]; }
+            for (int j = 0; j < RANK; j++) FA_LDS_ADD(sK[gs + P.off[i][j]], R.Kuu[i][b * RANK + j]);
+            if constexpr (KEEP) { if (P.keep2) FA_LDS_ADD(sK[gs + P.off[i][RANK]], R.Kup[i][b]); }
           }
         }
         if constexpr (PF) {
 #pragma unroll
           for (int b = 0; b < NPE; b++) {
             const int gs = rs[RANK] + (int)ps[b] * P.cnt[RANK];
-            sK[gs + P.off[RANK][RANK]] += R.Kpp[b];
+            FA_LDS_ADD(sK[gs + P.off[RANK][RANK]], R.Kpp[b]);
             if constexpr (KEEP) {
               if (P.keep3) {
 #pragma unroll
-                for (int j = 0; j < RANK; j++) sK[gs + P.off[RANK][j]] += R.Kpu[b * RANK + j];
+                for (int j = 0; j < RANK; j++) FA_LDS_ADD(sK[gs + P.off[RANK][j]], R.Kpu[b * RANK + j]);
               }
             }
           }
@@ -476,6 +514,9 @@ __global__ __launch_bounds__(kBlock) void assemble_rows(const Params P) {
   }
 
   // ---- stream the finished rows out, coalesced ----
+#if defined(FA_ABLATE) && (FA_ABLATE & 1)
+  if (len < 0)
+#endif
   if constexpr (WANT_K) {
     double* __restrict__ Kg = P.K + base;
     if (P.overwrite) for (int i = tid; i < len; i += kBlock) Kg[i] = sK[i];
@@ -515,8 +556,8 @@ __device__ __forceinline__ int64_t find_col(const Params& P, int64_t row, int64_
 }
 
 template <class SH, int FAM, bool WANT_K, bool KEEP>
-__global__ __launch_bounds__(kBlock) void assemble_generic(const Params P) {
-  constexpr int RANK = SH::RANK, NPE = SH::NPE;
+__global__ __launch_bounds__(SH::BLOCK) void assemble_generic(const Params P) {
+  constexpr int RANK = SH::RANK, NPE = SH::NPE, kBlock = SH::BLOCK;
   constexpr bool PF = (FAM != FAM_LE);
   constexpr int NDOF = PF ? RANK + 1 : RANK;
   __shared__ double sErr[kBlock / 64];
@@ -587,8 +628,8 @@ __global__ __launch_bounds__(kBlock) void assemble_generic(const Params P) {
 // ------------------------------------------------------------------------------------------------
 template <class SH, int FAM, bool WANT_K, bool KEEP>
 static int launch_one(const Params& P, bool rows, int grid, hipStream_t st) {
-  if (rows) hipLaunchKernelGGL((assemble_rows<SH, FAM, WANT_K, KEEP>), dim3(grid), dim3(kBlock), 0, st, P);
-  else      hipLaunchKernelGGL((assemble_generic<SH, FAM, WANT_K, KEEP>), dim3(grid), dim3(kBlock), 0, st, P);
+  if (rows) hipLaunchKernelGGL((assemble_rows<SH, FAM, WANT_K, KEEP>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
+  else      hipLaunchKernelGGL((assemble_generic<SH, FAM, WANT_K, KEEP>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
   return (int)hipGetLastError();
 }
 
