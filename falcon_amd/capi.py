@@ -18,7 +18,7 @@ HOOKE, AMOR_PHASE, BOURDIN_PHASE, MIEHE_PHASE = range(4)
 PLANE_STRAIN, PLANE_STRESS = 0, 1
 AT1, AT2, CZM_LINEAR, CZM_EXPONENTIAL, CZM_CORNELISSEN, CZM_HYPERBOLIC = range(6)
 PATTERN_FULL, PATTERN_WRITTEN = 0, 1
-ACCUMULATE, OVERWRITE, STORE_STRAIN, FORCE_GENERIC = 0, 1, 2, 4
+ACCUMULATE, OVERWRITE, STORE_STRAIN, FORCE_GENERIC, DETERMINISTIC = 0, 1, 2, 4, 8
 
 SHAPE_INFO = {  # shape id -> (rank, npe, nip)
     TRI3_G1: (2, 3, 1), TRI3_G3: (2, 3, 3), QUAD4_G2: (2, 4, 4), QUAD8_G3: (2, 8, 9), QUAD8_G2: (2, 8, 4),
@@ -49,7 +49,7 @@ class AssembleArgs(C.Structure):
 
 
 EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_nip_total", "fa_ndof_per_node",
-           "fa_strain_rows", "fa_uses_row_kernel", "fa_psi0", "fa_pattern_host", "fa_pattern_device",
+           "fa_strain_rows", "fa_uses_row_kernel", "fa_psi0", "fa_patch_stats", "fa_pattern_host", "fa_pattern_device",
            "fa_assemble", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
            "fa_history_device", "fa_get_strain_cache"]
 
@@ -71,6 +71,7 @@ def lib():
         for name in ("fa_ndof_per_node", "fa_strain_rows", "fa_uses_row_kernel"):
             getattr(L, name).argtypes = [vp]; getattr(L, name).restype = C.c_int32
         L.fa_psi0.argtypes = [vp]; L.fa_psi0.restype = C.c_double
+        L.fa_patch_stats.argtypes = [vp, C.POINTER(C.c_double)]; L.fa_patch_stats.restype = C.c_int32
         L.fa_pattern_host.argtypes = [vp, vp, vp]
         L.fa_pattern_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
         L.fa_assemble.argtypes = [vp, C.POINTER(AssembleArgs)]
@@ -127,6 +128,9 @@ class Assembler:
         self.strain_rows = L.fa_strain_rows(self.h)
         self.uses_row_kernel = bool(L.fa_uses_row_kernel(self.h))
         self.psi0 = L.fa_psi0(self.h)
+        red = C.c_double(1.0)
+        self.npatch = L.fa_patch_stats(self.h, C.byref(red))
+        self.redundancy = red.value
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:

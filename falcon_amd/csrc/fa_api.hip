@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -17,6 +18,7 @@
 
 #include "../../include/falcon_assemble.h"
 #include "fa_internal.h"
+#include "fa_patches.h"
 
 namespace {
 
@@ -147,13 +149,17 @@ struct fa_ctx {
   int rank = 0, npe = 0, nip = 0, str = 0, ndofpn = 0, fam = 0, srows = 0;
   int64_t nnode = 0, nel = 0, ndof = 0, nnz = 0;
   bool rows_path = false, own_pattern = false;
-  int nwg = 0, max_valence = 0, ngrid_generic = 0, block = 0;
+  int nwg = 0, max_valence = 0, ngrid_generic = 0, block = 0, npatch = 0, plds = 0;
+  bool patch_path = false;
+  double lane_redundancy = 1.0;
   fa::launch_fn launch = nullptr;
   fa::Params P{};
   // device
   int32_t* d_conn = nullptr; double* d_coords = nullptr; int64_t* d_row_ptr = nullptr; int32_t* d_col_idx = nullptr;
   int64_t* d_node_dofs = nullptr; int32_t* d_n2e_ptr = nullptr; int32_t* d_n2e_ent = nullptr; uint8_t* d_pos = nullptr;
   int32_t* d_wg_start = nullptr; double* d_tab = nullptr;
+  int32_t *d_pn_ptr = nullptr, *d_pe_ptr = nullptr, *d_pr_ptr = nullptr, *d_pnode = nullptr, *d_poff = nullptr,
+          *d_prec = nullptr, *d_prun = nullptr;
   double* d_hist[2] = { nullptr, nullptr };   // [0] preHist_, [1] newHist_
   double* d_strain = nullptr; double* d_err_part = nullptr;
   // staging for fa_assemble_host
@@ -168,7 +174,8 @@ extern "C" void fa_destroy(fa_ctx* c) {
   (void)hipSetDevice(c->prob.device);
   void* ptrs[] = { c->d_conn, c->d_coords, c->d_row_ptr, c->d_col_idx, c->d_node_dofs, c->d_n2e_ptr, c->d_n2e_ent,
                    c->d_pos, c->d_wg_start, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part,
-                   c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err };
+                   c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err,
+                   c->d_pn_ptr, c->d_pe_ptr, c->d_pr_ptr, c->d_pnode, c->d_poff, c->d_prec, c->d_prun };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete c;
 }
@@ -382,6 +389,21 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     wg_start.push_back((int32_t)nnode);
   }
   c->rows_path = rows_ok;
+  // ---- node patches (patch kernel) ----
+  fa::PatchSet ps;
+  if (rows_ok && nel > 0 && getenv("FA_USE_PATCH")) {               // experimental, opt-in
+    int cap = (rank == 2) ? 6144 : 16384;                       // doubles of LDS for the CSR image
+    if (const char* env = getenv("FA_PATCH_LDS")) cap = std::max(64, atoi(env));
+    const size_t lim = 160 * 1024;
+    while (fa::patch_shmem_bytes(cap, nd) > lim) cap -= 256;
+    c->patch_path = fa::build_patches(nnode, nel, npe, rank, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
+                                      pos.data(), h_rp, nd, cap, fa::kMaxOwn, ps);
+    if (c->patch_path) { c->npatch = ps.npatch; c->plds = ps.max_lds; c->lane_redundancy = ps.lane_redundancy; }
+    if (c->patch_path && getenv("FA_VERBOSE"))
+      fprintf(stderr, "[falcon_assemble] %d patches, %.1f nodes / %.1f elements / %.2f runs per patch, LDS image <= %d doubles, "
+              "Gauss-point redundancy %.3f\n", ps.npatch, (double)nnode / ps.npatch, (double)ps.nrec / ps.npatch,
+              (double)ps.prun.size() / ps.npatch, ps.max_lds, ps.lane_redundancy);
+  }
   c->nwg = rows_ok ? (int)wg_start.size() - 1 : 0;
   c->ngrid_generic = (int)((nel * npe + kBlock - 1) / kBlock);
 
@@ -397,6 +419,15 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   if ((st = upload(&c->d_n2e_ent, n2e_ent.data(), n2e_ent.size()))) return st;
   if ((st = upload(&c->d_pos, pos.data(), pos.size()))) return st;
   if (rows_ok) { if ((st = upload(&c->d_wg_start, wg_start.data(), wg_start.size()))) return st; }
+  if (c->patch_path) {
+    if ((st = upload(&c->d_pn_ptr, ps.pn_ptr.data(), ps.pn_ptr.size()))) return st;
+    if ((st = upload(&c->d_pe_ptr, ps.pe_ptr.data(), ps.pe_ptr.size()))) return st;
+    if ((st = upload(&c->d_pr_ptr, ps.pr_ptr.data(), ps.pr_ptr.size()))) return st;
+    if ((st = upload(&c->d_pnode, ps.pnode.data(), ps.pnode.size()))) return st;
+    if ((st = upload(&c->d_poff, ps.poff.data(), ps.poff.size()))) return st;
+    if ((st = upload(&c->d_prec, ps.prec.data(), ps.prec.size()))) return st;
+    if ((st = upload(&c->d_prun, ps.prun.data(), ps.prun.size()))) return st;
+  }
   {
     std::vector<double> tab;
     tab.insert(tab.end(), sh.N.begin(), sh.N.end());
@@ -412,12 +443,14 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[1], nipt, 0.0);
   }
   if (p->model == FA_PHASE_FRACTURE_EXTIT)
-    HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(c->nwg, c->ngrid_generic)));
+    HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(std::max(c->nwg, c->ngrid_generic), c->npatch)));
   HIP_TRY(hipDeviceSynchronize());
 
   P.conn = c->d_conn; P.coords = c->d_coords; P.row_ptr = c->d_row_ptr; P.col_idx = c->d_col_idx;
   P.node_dofs = c->d_node_dofs; P.n2e_ptr = c->d_n2e_ptr; P.n2e_ent = c->d_n2e_ent; P.pos = c->d_pos;
   P.wg_start = c->d_wg_start; P.tab = c->d_tab; P.max_valence = c->max_valence;
+  P.pn_ptr = c->d_pn_ptr; P.pe_ptr = c->d_pe_ptr; P.pr_ptr = c->d_pr_ptr; P.pnode = c->d_pnode; P.poff = c->d_poff;
+  P.prec = c->d_prec; P.prun = c->d_prun; P.plds = c->plds;
   return FA_OK;
 }
 
@@ -438,6 +471,7 @@ extern "C" int32_t fa_ndof_per_node(const fa_ctx* c) { return c->ndofpn; }
 extern "C" int32_t fa_strain_rows(const fa_ctx* c) { return c->srows; }
 extern "C" int32_t fa_uses_row_kernel(const fa_ctx* c) { return c->rows_path ? 1 : 0; }
 extern "C" double  fa_psi0(const fa_ctx* c) { return c->P.psi0; }
+extern "C" int32_t fa_patch_stats(const fa_ctx* c, double* red) { if (red) *red = c->lane_redundancy; return c->patch_path ? c->npatch : 0; }
 
 extern "C" fa_status fa_pattern_host(const fa_ctx* c, int64_t* row_ptr, int32_t* col_idx) {
   HIP_TRY(hipSetDevice(c->prob.device));
@@ -476,7 +510,9 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   P.err_part = want_err ? c->d_err_part : nullptr;
   const bool want_K = a->K_values != nullptr;
   const bool keep = want_K && (P.keep2 || P.keep3);
-  const bool rows = c->rows_path && !(a->flags & FA_FORCE_GENERIC);
+  int path = fa::PATH_GENERIC;
+  if (c->rows_path && !(a->flags & FA_FORCE_GENERIC))
+    path = (a->flags & FA_DETERMINISTIC) ? fa::PATH_ROWS_ORDERED : (c->patch_path ? fa::PATH_PATCH : fa::PATH_ROWS);
   if (c->nel == 0) {
     if (P.overwrite) {
       if (want_K) HIP_TRY(hipMemsetAsync(a->K_values, 0, sizeof(double) * c->nnz, st));
@@ -486,7 +522,8 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
     return FA_OK;
   }
   int grid;
-  if (rows) grid = c->nwg;
+  if (path == fa::PATH_PATCH) grid = c->npatch;
+  else if (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) grid = c->nwg;
   else {
     grid = c->ngrid_generic;
     if (P.overwrite) {
@@ -494,7 +531,7 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
       HIP_TRY(hipMemsetAsync(a->f_int, 0, sizeof(double) * c->ndof, st));
     }
   }
-  int rc = c->launch(P, c->fam, want_K, keep, rows, grid, (void*)st);
+  int rc = c->launch(P, c->fam, want_K, keep, path, grid, (void*)st);
   if (rc == -1000) return fail(FA_ERR_UNSUPPORTED, "kernel family not built for this shape");
   if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   if (want_err) {

@@ -18,6 +18,22 @@ namespace fa {
 constexpr int block_for(int rank) { return rank == 2 ? FA_BLOCK2D : 256; }
 constexpr int lds_for(int rank)   { return rank == 2 ? FA_LDS2D : 12288; }
 
+// patch kernel geometry
+#ifndef FA_PBLOCK
+#define FA_PBLOCK 256
+#endif
+constexpr int kMaxOwn = 256;                          // owned nodes per patch (LDS tables)
+constexpr int pblock_for(int npe) { return (FA_PBLOCK / npe) * npe; }   // threads: whole NPE-lane groups
+constexpr size_t patch_shmem_bytes(int plds, int ndofpn) {     // K image, f image, global offsets, 4 int tables
+  return sizeof(double) * ((size_t)plds + (size_t)kMaxOwn * ndofpn + kMaxOwn) + sizeof(int) * (4 * (size_t)kMaxOwn + 2);
+}
+// per patch-element record (int32 words): element id, its NPE nodes, NPE owned indices (u16, 0xFFFF = node of
+// another patch), NPE rows of NPE column positions (u8)
+constexpr int prec_own_words(int npe) { return (npe + 1) / 2; }
+constexpr int prec_pos_words(int npe) { return (npe + 3) / 4; }
+constexpr int prec_stride(int npe) { return 1 + npe + prec_own_words(npe) + npe * prec_pos_words(npe); }
+enum { PATH_PATCH = 0, PATH_ROWS = 1, PATH_GENERIC = 2, PATH_ROWS_ORDERED = 3 };
+
 // kernel family: which compute core is instantiated
 enum { FAM_LE = 0, FAM_PF_ISO = 1, FAM_PF_MIEHE = 2 };
 
@@ -31,7 +47,15 @@ struct Params {
   const int32_t* n2e_ptr;    // nnode+1   node -> incident (element, local node) pairs, element-ascending
   const int32_t* n2e_ent;    // nel*npe   e*npe + la
   const uint8_t* pos;        // nel*npe*npe: position of node conn[e][lb] in the sorted neighbour list of conn[e][la]
-  const int32_t* wg_start;   // nwg+1     first node of every workgroup
+  const int32_t* wg_start;   // nwg+1     first node of every workgroup (row kernel)
+  // patch kernel: node patches with their halo of elements
+  const int32_t* pn_ptr;     // npatch+1  owned nodes of patch p: pnode[pn_ptr[p] .. pn_ptr[p+1]), ascending ids
+  const int32_t* pe_ptr;     // npatch+1  elements touching patch p: pelem[pe_ptr[p] .. pe_ptr[p+1])
+  const int32_t* pr_ptr;     // npatch+1  runs of consecutive node ids
+  const int32_t* pnode;
+  const int32_t* poff;       // nnode+npatch  LDS offset of every owned node's row block, +1 sentinel per patch
+  const int32_t* prec;       // per patch element: record of prec_stride(npe) words (see above)
+  const int32_t* prun;       // first owned index | count << 16
   const double*  tab;        // shape tables: N[nip][npe], dN[nip][npe][rank], w[nip]
   // ---- vectors (device) ----
   const double*  state;
@@ -45,7 +69,7 @@ struct Params {
   double*        f;
   // ---- sizes / switches ----
   int64_t nnode, nel;
-  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted;
+  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds;
   int32_t cnt[4];            // entries per neighbour node in a row of dof type i
   int32_t off[4][4];         // offset of column type j inside that group, -1 if not in the pattern
   // ---- constants ----
@@ -56,9 +80,9 @@ struct Params {
 };
 
 // launchers, one translation unit per shape (fa_kernels_<shape>.hip)
-typedef int (*launch_fn)(const Params& P, int fam, bool want_K, bool keep, bool rows, int grid, void* stream);
-int launch_tri3_g1 (const Params&, int, bool, bool, bool, int, void*);
-int launch_quad4_g2(const Params&, int, bool, bool, bool, int, void*);
-int launch_hex8_g2 (const Params&, int, bool, bool, bool, int, void*);
+typedef int (*launch_fn)(const Params& P, int fam, bool want_K, bool keep, int path, int grid, void* stream);
+int launch_tri3_g1 (const Params&, int, bool, bool, int, int, void*);
+int launch_quad4_g2(const Params&, int, bool, bool, int, int, void*);
+int launch_hex8_g2 (const Params&, int, bool, bool, int, int, void*);
 
 }  // namespace fa

@@ -1,21 +1,29 @@
 // fa_kernel_impl.h -- gfx950 kernels for the element-level K / f_int assembly.
 //
-// Work decomposition ("owner computes", atomic-free):
-//   * one lane per (node a, incident element e) pair, i.e. per entry of the inverse connectivity
-//     n2e; lanes of one node are adjacent, a workgroup owns a contiguous node range [n0,n1);
-//   * the lane evaluates the Gauss-point loop of e (shape gradients, B, material update,
-//     degradation, history) and keeps only the rows of node a of the element blocks
-//     K1..K4 / f1,f2 (PhaseFractureModel.cpp:713-730) in registers;
-//   * the workgroup's slice of the CSR value array -- rows of nodes [n0,n1) are one contiguous
-//     range because dofs are node-major and rows column-sorted -- is mirrored in LDS; lanes add
-//     their row blocks into it in phases ordered by the lane's slot in the node's element list
-//     (two lanes of one phase never share a node => no atomics, and every CSR entry is summed in
-//     ascending element order exactly like the reference's serial element loop);
-//   * the LDS image is then streamed to HBM with fully coalesced stores, each K entry written once.
-// A generic fallback (any dof map / any CSR pattern) scatters the same row blocks with a per-entry
-// column search and FP64 atomics, like Jive's addBlock.
+// Three kernels share one Gauss-point core (ip_point / accum_rows):
+//
+//  assemble_patch  (opt-in, FA_USE_PATCH; experimental)  "owner computes" on 2-D/3-D node patches.  A workgroup owns a compact set
+//      of nodes; the slice of the CSR value array that holds their rows is mirrored in LDS.  Every
+//      element touching the patch gets a group of NPE adjacent lanes (lane la <-> local node la).  When
+//      NIP == NPE the group shares the Gauss-point work: lane la evaluates Gauss point la (Jacobian,
+//      gradients, strain, degradation, material update, history) and broadcasts that record inside the
+//      group with DPP quad permutes (NPE == 4) or ds_bpermute; each lane then keeps only the rows of its
+//      own node of K1..K4 / f1,f2 (PhaseFractureModel.cpp:713-730) and adds them into the LDS image with
+//      ds_add_f64.  Lanes whose node belongs to another patch only help with the Gauss points.  The LDS
+//      image is streamed to HBM in runs of consecutive nodes: coalesced, every K entry written once, no
+//      global atomics.
+//  assemble_rows   (default)  one lane per (node, incident element) pair on contiguous node ranges: the
+//      lane evaluates the element's Gauss points and keeps the rows of its node; the workgroup's rows are one
+//      contiguous slice of the CSR value array, mirrored in LDS, filled with ds_add_f64 and streamed out with
+//      coalesced stores.  With FA_DETERMINISTIC the lanes add in phases ordered by the element's slot in the
+//      node's element list instead, so every CSR entry is summed in ascending element order like the
+//      reference's serial loop (bitwise reproducible).
+//  assemble_generic  any dof map / any CSR pattern: per-entry column search + FP64 atomics, like
+//      MatrixBuilder::addBlock.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "fa_internal.h"
 
@@ -28,8 +36,16 @@ struct Shape {
   static constexpr int STR = (RANK_ == 2) ? 4 : 6;   // STRAIN_COUNTS (util/Constants.cpp:9)
   static constexpr int ND  = RANK_ * NPE_;
   static constexpr int BLOCK = block_for(RANK_), LDS = lds_for(RANK_);
-  static constexpr int MIN_WAVES = (RANK_ == 2) ? FA_WAVES2D : 1;   // waves per SIMD the register allocator must allow
+  static constexpr int PBLOCK = pblock_for(NPE_);
+  static constexpr bool SHARE = (NIP_ == NPE_) && (64 % NPE_ == 0);   // group shares the Gauss points
 };
+
+template <int I, int N>
+struct SFor {
+  template <class F> static __device__ __forceinline__ void run(F& f) { f(std::integral_constant<int, I>{}); SFor<I + 1, N>::run(f); }
+};
+template <int N>
+struct SFor<N, N> { template <class F> static __device__ __forceinline__ void run(F&) {} };
 
 template <class SH, bool WANT_K, bool PF, bool KEEP>
 struct RowBlock {
@@ -39,7 +55,70 @@ struct RowBlock {
   double Kpp[(WANT_K && PF) ? SH::NPE : 1];
   double Kup[(WANT_K && KEEP) ? SH::RANK : 1][(WANT_K && KEEP) ? SH::NPE : 1];
   double Kpu[(WANT_K && KEEP) ? SH::ND : 1];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < SH::RANK; i++) fu[i] = 0.0;
+    fp = 0.0;
+    if constexpr (WANT_K) {
+#pragma unroll
+      for (int i = 0; i < SH::RANK; i++)
+#pragma unroll
+        for (int j = 0; j < SH::ND; j++) Kuu[i][j] = 0.0;
+      if constexpr (PF) {
+#pragma unroll
+        for (int b = 0; b < SH::NPE; b++) Kpp[b] = 0.0;
+      }
+      if constexpr (KEEP) {
+#pragma unroll
+        for (int i = 0; i < SH::RANK; i++)
+#pragma unroll
+          for (int b = 0; b < SH::NPE; b++) Kup[i][b] = 0.0;
+#pragma unroll
+        for (int j = 0; j < SH::ND; j++) Kpu[j] = 0.0;
+      }
+    }
+  }
 };
+
+// Everything the row accumulation needs from one Gauss point.
+template <class SH, bool PF, bool KEEP>
+struct IpRec {
+  double w;                          // w_ref * det J
+  double g[SH::NPE][SH::RANK];       // dN_a/dx_i
+  double d0, d1, d3;                 // tangent D in isotropic form
+  double sig[SH::S];                 // stress
+  double sp[KEEP ? SH::S : 1];       // sigma+ = dPsi/deps (off-diagonal blocks only)
+  double c1, cf;                     // N N^T coefficient of K4; N coefficient of f2
+  double dg, dgl;                    // g'(phi), loading * g'(phi)
+  double gphi[PF ? SH::RANK : 1];    // grad phi
+};
+
+// gathered nodal data of one element
+template <class SH, bool PF>
+struct ElemData {
+  double x[SH::NPE][SH::RANK], u[SH::NPE][SH::RANK];
+  double phi[PF ? SH::NPE : 1], phi0[PF ? SH::NPE : 1], phiX[PF ? SH::NPE : 1];
+};
+
+template <class SH, bool PF>
+__device__ __forceinline__ void gather_elem(const Params& P, const int32_t (&cn)[SH::NPE], ElemData<SH, PF>& E) {
+  constexpr int RANK = SH::RANK, NPE = SH::NPE, NDOF = PF ? RANK + 1 : RANK;
+#pragma unroll
+  for (int a = 0; a < NPE; a++) {
+    const int64_t n = cn[a];
+    // XDofSpace::getDofIndices: node-major, type-minor unless the caller supplied its own dof map
+    int64_t dofs[NDOF];
+#pragma unroll
+    for (int i = 0; i < NDOF; i++) dofs[i] = P.node_dofs ? P.node_dofs[n * NDOF + i] : n * NDOF + i;
+#pragma unroll
+    for (int i = 0; i < RANK; i++) { E.x[a][i] = P.coords[n * RANK + i]; E.u[a][i] = P.state[dofs[i]]; }
+    if constexpr (PF) {
+      E.phi[a] = P.state[dofs[RANK]];
+      if (P.model >= 2) { E.phi0[a] = P.state0[dofs[RANK]]; E.phiX[a] = P.stateX[dofs[RANK]]; }
+      else { E.phi0[a] = 0.0; E.phiX[a] = 0.0; }
+    }
+  }
+}
 
 // rational degradation function and its derivatives (PhaseFractureModel.cpp:660-676).
 // ptype: 0 -> p = 2, 1 -> p = 2.5, 2 -> p = 4; pow(x,0) == 1 also at x == 0.
@@ -129,268 +208,239 @@ __device__ __forceinline__ void Bt_vec(const double (&ga)[RANK], const double (&
   }
 }
 
-// Gauss-point loop of element e, keeping the rows of local node la.
+// One Gauss point of element e: IShape::getShapeGradients, strain = B u, degradation, material update,
+// history (PhaseFractureModel.cpp:629-703; Ext variants PhaseFractureExtModel.cpp:656-758).
+// `ip` may differ from lane to lane.  `write` = this lane is the one that stores the per-point outputs
+// (history, strain cache, errExt_).
 template <class SH, int FAM, bool WANT_K, bool KEEP>
-__device__ __forceinline__ void compute_rowblock(const Params& P, int64_t e, int la, const int32_t (&cn)[SH::NPE],
-                                                 RowBlock<SH, WANT_K, FAM != FAM_LE, KEEP>& R, double& err_acc) {
-  // preHist_.H0_ of all Gauss points of e: one contiguous read, issued with the other gathers
-  double H0v[SH::NIP];
-  if constexpr (FAM != FAM_LE) {
-    if (P.model == 1) {
-#pragma unroll
-      for (int ip = 0; ip < SH::NIP; ip++) H0v[ip] = P.hist_pre[e * SH::NIP + ip];
-    }
-  }
+__device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, const ElemData<SH, FAM != FAM_LE>& E,
+                                         double H0, bool write, IpRec<SH, FAM != FAM_LE, KEEP>& r, double& err_acc) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, S = SH::S, STR = SH::STR;
   constexpr bool PF = (FAM != FAM_LE);
-  const int ndofpn = PF ? RANK + 1 : RANK;
   const double* __restrict__ tabN = P.tab;
   const double* __restrict__ tabD = P.tab + NIP * NPE;
   const double* __restrict__ tabW = P.tab + NIP * NPE * (1 + RANK);
 
-  double x[NPE][RANK], u[NPE][RANK];
-  double phi[PF ? NPE : 1], phi0[PF ? NPE : 1], phiX[PF ? NPE : 1];
+  double J[RANK][RANK];
+#pragma unroll
+  for (int i = 0; i < RANK; i++)
+#pragma unroll
+    for (int k = 0; k < RANK; k++) J[i][k] = 0.0;
+  double dn[NPE][RANK];
+#pragma unroll
+  for (int a = 0; a < NPE; a++)
+#pragma unroll
+    for (int k = 0; k < RANK; k++) dn[a][k] = tabD[(ip * NPE + a) * RANK + k];
+#pragma unroll
+  for (int a = 0; a < NPE; a++)
+#pragma unroll
+    for (int i = 0; i < RANK; i++)
+#pragma unroll
+      for (int k = 0; k < RANK; k++) J[i][k] += E.x[a][i] * dn[a][k];
+  double inv[RANK][RANK], det;
+  if constexpr (RANK == 2) {
+    det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    const double rd = 1.0 / det;
+    inv[0][0] = J[1][1] * rd;  inv[0][1] = -J[0][1] * rd;
+    inv[1][0] = -J[1][0] * rd; inv[1][1] = J[0][0] * rd;
+  } else {
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double rd = 1.0 / det;
+    inv[0][0] = c00 * rd;
+    inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
+    inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * rd;
+    inv[1][0] = c01 * rd;
+    inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * rd;
+    inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rd;
+    inv[2][0] = c02 * rd;
+    inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
+    inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
+  }
+  r.w = tabW[ip] * det;
+#pragma unroll
+  for (int a = 0; a < NPE; a++)
+#pragma unroll
+    for (int i = 0; i < RANK; i++) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < RANK; k++) s += dn[a][k] * inv[k][i];
+      r.g[a][i] = s;
+    }
+  // ---- strain = B u (ShapeUtils.cpp:73-145); 2D keeps xx, yy, gamma_xy ----
+  double eps[S];
+#pragma unroll
+  for (int c = 0; c < S; c++) eps[c] = 0.0;
 #pragma unroll
   for (int a = 0; a < NPE; a++) {
-    const int64_t n = cn[a];
-    // XDofSpace::getDofIndices: node-major, type-minor unless the caller supplied its own dof map
-    int64_t dofs[PF ? RANK + 1 : RANK];
-#pragma unroll
-    for (int i = 0; i < (PF ? RANK + 1 : RANK); i++)
-      dofs[i] = P.node_dofs ? P.node_dofs[n * ndofpn + i] : n * ndofpn + i;
-#pragma unroll
-    for (int i = 0; i < RANK; i++) { x[a][i] = P.coords[n * RANK + i]; u[a][i] = P.state[dofs[i]]; }
-    if constexpr (PF) {
-      phi[a] = P.state[dofs[RANK]];
-      if (P.model >= 2) { phi0[a] = P.state0[dofs[RANK]]; phiX[a] = P.stateX[dofs[RANK]]; }
-      else { phi0[a] = 0.0; phiX[a] = 0.0; }
-    }
-  }
-
-#pragma unroll
-  for (int i = 0; i < RANK; i++) R.fu[i] = 0.0;
-  R.fp = 0.0;
-  if constexpr (WANT_K) {
-#pragma unroll
-    for (int i = 0; i < RANK; i++)
-#pragma unroll
-      for (int j = 0; j < SH::ND; j++) R.Kuu[i][j] = 0.0;
-    if constexpr (PF) {
-#pragma unroll
-      for (int b = 0; b < NPE; b++) R.Kpp[b] = 0.0;
-    }
-    if constexpr (KEEP) {
-#pragma unroll
-      for (int i = 0; i < RANK; i++)
-#pragma unroll
-        for (int b = 0; b < NPE; b++) R.Kup[i][b] = 0.0;
-#pragma unroll
-      for (int j = 0; j < SH::ND; j++) R.Kpu[j] = 0.0;
-    }
-  }
-
-#pragma unroll 1
-  for (int ip = 0; ip < NIP; ip++) {
-    // ---- IShape::getShapeGradients: J = sum_a x_a (x) dN_a/dxi, grads = dN J^{-1}, w = w_ref det J ----
-    double J[RANK][RANK];
-#pragma unroll
-    for (int i = 0; i < RANK; i++)
-#pragma unroll
-      for (int k = 0; k < RANK; k++) J[i][k] = 0.0;
-#pragma unroll
-    for (int a = 0; a < NPE; a++)
-#pragma unroll
-      for (int i = 0; i < RANK; i++)
-#pragma unroll
-        for (int k = 0; k < RANK; k++) J[i][k] += x[a][i] * tabD[(ip * NPE + a) * RANK + k];
-    double inv[RANK][RANK], det;
     if constexpr (RANK == 2) {
-      det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-      const double r = 1.0 / det;
-      inv[0][0] = J[1][1] * r;  inv[0][1] = -J[0][1] * r;
-      inv[1][0] = -J[1][0] * r; inv[1][1] = J[0][0] * r;
+      eps[0] += r.g[a][0] * E.u[a][0];
+      eps[1] += r.g[a][1] * E.u[a][1];
+      eps[2] += r.g[a][1] * E.u[a][0]; eps[2] += r.g[a][0] * E.u[a][1];
     } else {
-      const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-      const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-      const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-      det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-      const double r = 1.0 / det;
-      inv[0][0] = c00 * r;
-      inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
-      inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
-      inv[1][0] = c01 * r;
-      inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
-      inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
-      inv[2][0] = c02 * r;
-      inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
-      inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+      eps[0] += r.g[a][0] * E.u[a][0];
+      eps[1] += r.g[a][1] * E.u[a][1];
+      eps[2] += r.g[a][2] * E.u[a][2];
+      eps[3] += r.g[a][1] * E.u[a][0]; eps[3] += r.g[a][0] * E.u[a][1];
+      eps[4] += r.g[a][2] * E.u[a][1]; eps[4] += r.g[a][1] * E.u[a][2];
+      eps[5] += r.g[a][0] * E.u[a][2]; eps[5] += r.g[a][2] * E.u[a][0];
     }
-    const double w = tabW[ip] * det;
-    double g[NPE][RANK];
+  }
+  const int64_t ipoint = e * NIP + ip;               // initializeIPMPMap_, PhaseFractureModel.cpp:1070-1093
+  const int srows = PF ? STR + 1 : STR;
+  if (P.strain != nullptr && write) {
+    double* sc = P.strain + ipoint * srows;
+    if constexpr (RANK == 2) { sc[0] = eps[0]; sc[1] = eps[1]; sc[2] = 0.0; sc[3] = eps[2]; }
+    else {
 #pragma unroll
-    for (int a = 0; a < NPE; a++)
+      for (int c = 0; c < S; c++) sc[c] = eps[c];
+    }
+  }
+
+  double sp[S], Psi = 0.0;
+  r.c1 = 0.0; r.cf = 0.0; r.dg = 0.0; r.dgl = 0.0;
+  if constexpr (!PF) {
+    iso_update<RANK, S>(P, eps, 1.0, r.d0, r.d1, r.d3, r.sig, sp, Psi);
+  } else {
+    double pf = 0.0, pf0 = 0.0, dgphi, ddgphi, loading = 1.0;
 #pragma unroll
-      for (int i = 0; i < RANK; i++) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < RANK; k++) s += tabD[(ip * NPE + a) * RANK + k] * inv[k][i];
-        g[a][i] = s;
-      }
-    // ---- strain = B u (ShapeUtils.cpp:73-145); 2D keeps xx, yy, gamma_xy ----
-    double eps[S];
-#pragma unroll
-    for (int c = 0; c < S; c++) eps[c] = 0.0;
+    for (int i = 0; i < RANK; i++) r.gphi[i] = 0.0;
 #pragma unroll
     for (int a = 0; a < NPE; a++) {
-      if constexpr (RANK == 2) {
-        eps[0] += g[a][0] * u[a][0];
-        eps[1] += g[a][1] * u[a][1];
-        eps[2] += g[a][1] * u[a][0]; eps[2] += g[a][0] * u[a][1];
-      } else {
-        eps[0] += g[a][0] * u[a][0];
-        eps[1] += g[a][1] * u[a][1];
-        eps[2] += g[a][2] * u[a][2];
-        eps[3] += g[a][1] * u[a][0]; eps[3] += g[a][0] * u[a][1];
-        eps[4] += g[a][2] * u[a][1]; eps[4] += g[a][1] * u[a][2];
-        eps[5] += g[a][0] * u[a][2]; eps[5] += g[a][2] * u[a][0];
-      }
-    }
-    const bool owner = ((ip % NPE) == la);             // exactly one lane of the element owns each ip
-    const int64_t ipoint = e * NIP + ip;               // initializeIPMPMap_, PhaseFractureModel.cpp:1070-1093
-    const int srows = PF ? STR + 1 : STR;
-    if (P.strain != nullptr && owner) {
-      double* sc = P.strain + ipoint * srows;
-      if constexpr (RANK == 2) { sc[0] = eps[0]; sc[1] = eps[1]; sc[2] = 0.0; sc[3] = eps[2]; }
-      else {
+      pf += tabN[ip * NPE + a] * E.phi[a];
 #pragma unroll
-        for (int c = 0; c < S; c++) sc[c] = eps[c];
-      }
+      for (int i = 0; i < RANK; i++) r.gphi[i] += r.g[a][i] * E.phi[a];
     }
+    double gmat;
+    if (P.model == 1) {
+      degrade(P, pf, gmat, dgphi, ddgphi);
+    } else {
+      // extrapolated phase field (PhaseFractureExtModel.cpp:656-691, PhaseFractureExtItModel.cpp:693)
+      double pfX = 0.0;
+#pragma unroll
+      for (int a = 0; a < NPE; a++) { pf0 += tabN[ip * NPE + a] * E.phi0[a]; pfX += tabN[ip * NPE + a] * E.phiX[a]; }
+      double pfEx;
+      if (P.model == 2) {
+        if (P.dt0 < 1.e-15) pfEx = pf0;
+        else                pfEx = -pfX * P.dt / P.dt0 + pf0 * (P.dt + P.dt0) / P.dt0;
+      } else {
+        pfEx = pfX;
+        if (write) { const double d = pf - pfEx; err_acc += d * d; }
+      }
+      if (pfEx < 0.0) pfEx = 0.0; else if (pfEx > 1.0) pfEx = 1.0;
+      double t1, t2, t3;
+      degrade(P, pfEx, gmat, t1, t2);
+      degrade(P, pf, t3, dgphi, ddgphi);
+    }
+    if (P.strain != nullptr && write) P.strain[ipoint * srows + STR] = gmat;
+    iso_update<RANK, S>(P, eps, gmat, r.d0, r.d1, r.d3, r.sig, sp, Psi);
+    if (P.model == 1) {                                 // PhaseFractureModel.cpp:696-703
+      if (Psi < H0) loading = 0.0;
+      Psi = (Psi > H0) ? Psi : H0;
+      if (write) P.hist_new[ipoint] = Psi;
+    } else {
+      Psi = (Psi > P.psi0) ? Psi : P.psi0;              // PhaseFractureExtModel.cpp:726
+    }
+    const double dw = P.eta + 2.0 * (1.0 - P.eta) * pf, ddw = 2.0 * (1.0 - P.eta);
+    r.c1 = P.gcl * ddw + ddgphi * Psi;                  // K4 (:714)
+    r.cf = P.gcl * dw + dgphi * Psi;                    // f2 (:728)
+    if ((P.model >= 2) && (pf0 - pf > 1.e-15)) {        // penalty, PhaseFractureExtModel.cpp:752-758
+      r.c1 += P.gcl * P.beta;
+      r.cf -= P.gcl * P.beta * (pf0 - pf);
+    }
+    r.dg = dgphi; r.dgl = loading * dgphi;
+  }
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int c = 0; c < S; c++) r.sp[c] = sp[c];
+  }
+}
 
-    double d0, d1, d3, sig[S], sp[S], Psi = 0.0;
-    double dgphi = 0.0, ddgphi = 0.0, pf = 0.0, pf0 = 0.0, loading = 1.0;
-    double gradphi[RANK];
-    if constexpr (!PF) {
-      iso_update<RANK, S>(P, eps, 1.0, d0, d1, d3, sig, sp, Psi);
+// Rows of local node la from one Gauss-point record.  Nip[b] = N_b(ip).
+template <class SH, int FAM, bool WANT_K, bool KEEP>
+__device__ __forceinline__ void accum_rows(const Params& P, const IpRec<SH, FAM != FAM_LE, KEEP>& r, int la,
+                                           const double (&Nip)[SH::NPE],
+                                           RowBlock<SH, WANT_K, FAM != FAM_LE, KEEP>& R) {
+  constexpr int RANK = SH::RANK, NPE = SH::NPE, S = SH::S;
+  constexpr bool PF = (FAM != FAM_LE);
+  double wga[RANK], Nla = 0.0;                        // w * grad N_la (select: no runtime register indexing)
+#pragma unroll
+  for (int i = 0; i < RANK; i++) wga[i] = 0.0;
+#pragma unroll
+  for (int a = 0; a < NPE; a++)
+    if (a == la) {
+#pragma unroll
+      for (int i = 0; i < RANK; i++) wga[i] = r.w * r.g[a][i];
+      Nla = Nip[a];
+    }
+  {
+    double t[RANK];
+    Bt_vec<RANK, S>(wga, r.sig, t);                   // f1 += w B^T sigma (:727)
+#pragma unroll
+    for (int i = 0; i < RANK; i++) R.fu[i] += t[i];
+  }
+  if constexpr (WANT_K) {
+    if constexpr (RANK == 2) {                        // K1 += w B_a^T D B_b (:713)
+      const double a00 = wga[0] * r.d0, a01 = wga[0] * r.d1, a03 = wga[0] * r.d3;
+      const double a10 = wga[1] * r.d0, a11 = wga[1] * r.d1, a13 = wga[1] * r.d3;
+#pragma unroll
+      for (int b = 0; b < NPE; b++) {
+        const double gbx = r.g[b][0], gby = r.g[b][1];
+        R.Kuu[0][2 * b]     += a00 * gbx + a13 * gby;
+        R.Kuu[0][2 * b + 1] += a01 * gby + a13 * gbx;
+        R.Kuu[1][2 * b]     += a11 * gbx + a03 * gby;
+        R.Kuu[1][2 * b + 1] += a10 * gby + a03 * gbx;
+      }
     } else {
 #pragma unroll
-      for (int i = 0; i < RANK; i++) gradphi[i] = 0.0;
+      for (int b = 0; b < NPE; b++) {
+        const double dotp = wga[0] * r.g[b][0] + wga[1] * r.g[b][1] + wga[2] * r.g[b][2];
 #pragma unroll
-      for (int a = 0; a < NPE; a++) {
-        pf += tabN[ip * NPE + a] * phi[a];
+        for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int i = 0; i < RANK; i++) gradphi[i] += g[a][i] * phi[a];
-      }
-      double gmat;
-      if (P.model == 1) {
-        degrade(P, pf, gmat, dgphi, ddgphi);
-      } else {
-        // extrapolated phase field (PhaseFractureExtModel.cpp:656-691, PhaseFractureExtItModel.cpp:693)
-        double pfX = 0.0;
-#pragma unroll
-        for (int a = 0; a < NPE; a++) { pf0 += tabN[ip * NPE + a] * phi0[a]; pfX += tabN[ip * NPE + a] * phiX[a]; }
-        double pfEx;
-        if (P.model == 2) {
-          if (P.dt0 < 1.e-15) pfEx = pf0;
-          else                pfEx = -pfX * P.dt / P.dt0 + pf0 * (P.dt + P.dt0) / P.dt0;
-        } else {
-          pfEx = pfX;
-          if (owner) { const double d = pf - pfEx; err_acc += d * d; }
-        }
-        if (pfEx < 0.0) pfEx = 0.0; else if (pfEx > 1.0) pfEx = 1.0;
-        double t1, t2, t3;
-        degrade(P, pfEx, gmat, t1, t2);
-        degrade(P, pf, t3, dgphi, ddgphi);
-      }
-      if (P.strain != nullptr && owner) P.strain[ipoint * srows + STR] = gmat;
-      iso_update<RANK, S>(P, eps, gmat, d0, d1, d3, sig, sp, Psi);
-      if (P.model == 1) {
-        const double H0 = H0v[ip];                      // PhaseFractureModel.cpp:696-703
-        if (Psi < H0) loading = 0.0;
-        Psi = (Psi > H0) ? Psi : H0;
-        if (owner) P.hist_new[ipoint] = Psi;
-      } else {
-        Psi = (Psi > P.psi0) ? Psi : P.psi0;            // PhaseFractureExtModel.cpp:726
-      }
-    }
-
-    // ---- rows of node la ----
-    double wga[RANK];                                 // w * grad N_la (select, no runtime register indexing)
-    double Nla = 0.0;
-#pragma unroll
-    for (int a = 0; a < NPE; a++)
-      if (a == la) {
-#pragma unroll
-        for (int i = 0; i < RANK; i++) wga[i] = w * g[a][i];
-        Nla = tabN[ip * NPE + a];
-      }
-    {
-      double t[RANK];
-      Bt_vec<RANK, S>(wga, sig, t);                     // f1 += w B^T sigma (:727)
-#pragma unroll
-      for (int i = 0; i < RANK; i++) R.fu[i] += t[i];
-    }
-    if constexpr (WANT_K) {
-#pragma unroll
-      for (int b = 0; b < NPE; b++) {                   // K1 += w B_a^T D B_b (:713)
-        if constexpr (RANK == 2) {
-          const double gbx = g[b][0], gby = g[b][1];
-          R.Kuu[0][2 * b]     += (wga[0] * d0) * gbx + (wga[1] * d3) * gby;
-          R.Kuu[0][2 * b + 1] += (wga[0] * d1) * gby + (wga[1] * d3) * gbx;
-          R.Kuu[1][2 * b]     += (wga[1] * d1) * gbx + (wga[0] * d3) * gby;
-          R.Kuu[1][2 * b + 1] += (wga[1] * d0) * gby + (wga[0] * d3) * gbx;
-        } else {
-          const double dotp = wga[0] * g[b][0] + wga[1] * g[b][1] + wga[2] * g[b][2];
-#pragma unroll
-          for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-              if (i == j) R.Kuu[i][3 * b + j] += (d0 - d3) * (wga[i] * g[b][i]) + d3 * dotp;
-              else        R.Kuu[i][3 * b + j] += d1 * (wga[i] * g[b][j]) + d3 * (wga[j] * g[b][i]);
-            }
-        }
-      }
-    }
-    if constexpr (PF) {
-      const double wNa = w * Nla;
-      double gg = 0.0;
-#pragma unroll
-      for (int i = 0; i < RANK; i++) gg += wga[i] * gradphi[i];
-      const double dw = P.eta + 2.0 * (1.0 - P.eta) * pf;
-      R.fp += wNa * (P.gcl * dw + dgphi * Psi) + P.c2 * gg;            // f2 (:728-730)
-      const bool pen = (P.model >= 2) && (pf0 - pf > 1.e-15);           // PhaseFractureExtModel.cpp:752-758
-      if (pen) R.fp -= wNa * (P.gcl * P.beta * (pf0 - pf));
-      if constexpr (WANT_K) {
-        const double ddw = 2.0 * (1.0 - P.eta);
-        double c1 = P.gcl * ddw + ddgphi * Psi;
-        if (pen) c1 += P.gcl * P.beta;
-#pragma unroll
-        for (int b = 0; b < NPE; b++) {                                 // K4 (:714-716)
-          double gab = 0.0;
-#pragma unroll
-          for (int i = 0; i < RANK; i++) gab += wga[i] * g[b][i];
-          R.Kpp[b] += (wNa * c1) * tabN[ip * NPE + b] + P.c2 * gab;
-        }
-        if constexpr (KEEP) {
-          if (P.keep2) {                                                // K2 += w g' B^T (sigma+ (x) N) (:720)
-            double t[RANK];
-            Bt_vec<RANK, S>(wga, sp, t);
-#pragma unroll
-            for (int i = 0; i < RANK; i++)
-#pragma unroll
-              for (int b = 0; b < NPE; b++) R.Kup[i][b] += (dgphi * t[i]) * tabN[ip * NPE + b];
+          for (int j = 0; j < 3; j++) {
+            if (i == j) R.Kuu[i][3 * b + j] += (r.d0 - r.d3) * (wga[i] * r.g[b][i]) + r.d3 * dotp;
+            else        R.Kuu[i][3 * b + j] += r.d1 * (wga[i] * r.g[b][j]) + r.d3 * (wga[j] * r.g[b][i]);
           }
-          if (P.keep3) {                                                // K3 += w loading g' N (x) (sigma+^T B) (:721)
-            const double c = wNa * loading * dgphi;
+      }
+    }
+  }
+  if constexpr (PF) {
+    const double wNa = r.w * Nla;
+    double gg = 0.0;
 #pragma unroll
-            for (int b = 0; b < NPE; b++) {
-              double t[RANK], gb[RANK];
+    for (int i = 0; i < RANK; i++) gg += wga[i] * r.gphi[i];
+    R.fp += wNa * r.cf + P.c2 * gg;                                   // f2 (:728-730)
+    if constexpr (WANT_K) {
+      const double wc1 = wNa * r.c1;
 #pragma unroll
-              for (int i = 0; i < RANK; i++) gb[i] = g[b][i];
-              Bt_vec<RANK, S>(gb, sp, t);
+      for (int b = 0; b < NPE; b++) {                                 // K4 (:714-716)
+        double gab = 0.0;
 #pragma unroll
-              for (int j = 0; j < RANK; j++) R.Kpu[b * RANK + j] += c * t[j];
-            }
+        for (int i = 0; i < RANK; i++) gab += wga[i] * r.g[b][i];
+        R.Kpp[b] += wc1 * Nip[b] + P.c2 * gab;
+      }
+      if constexpr (KEEP) {
+        if (P.keep2) {                                                // K2 += w g' B^T (sigma+ (x) N) (:720)
+          double t[RANK];
+          Bt_vec<RANK, S>(wga, r.sp, t);
+#pragma unroll
+          for (int i = 0; i < RANK; i++)
+#pragma unroll
+            for (int b = 0; b < NPE; b++) R.Kup[i][b] += (r.dg * t[i]) * Nip[b];
+        }
+        if (P.keep3) {                                                // K3 += w loading g' N (x) (sigma+^T B) (:721)
+          const double c = wNa * r.dgl;
+#pragma unroll
+          for (int b = 0; b < NPE; b++) {
+            double t[RANK], gb[RANK];
+#pragma unroll
+            for (int i = 0; i < RANK; i++) gb[i] = r.g[b][i];
+            Bt_vec<RANK, S>(gb, r.sp, t);
+#pragma unroll
+            for (int j = 0; j < RANK; j++) R.Kpu[b * RANK + j] += c * t[j];
           }
         }
       }
@@ -398,11 +448,294 @@ __device__ __forceinline__ void compute_rowblock(const Params& P, int64_t e, int
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Row-gather kernel (canonical node-major dofs, column-sorted blocked pattern)
-// ------------------------------------------------------------------------------------------------
+// Gauss-point loop of element e done by ONE lane, keeping the rows of local node la.
 template <class SH, int FAM, bool WANT_K, bool KEEP>
-__global__ __launch_bounds__(SH::BLOCK, SH::MIN_WAVES) void assemble_rows(const Params P) {
+__device__ __forceinline__ void compute_rowblock(const Params& P, int64_t e, int la, const int32_t (&cn)[SH::NPE],
+                                                 bool owned, RowBlock<SH, WANT_K, FAM != FAM_LE, KEEP>& R,
+                                                 double& err_acc) {
+  constexpr int NPE = SH::NPE, NIP = SH::NIP;
+  constexpr bool PF = (FAM != FAM_LE);
+  double H0v[NIP];                                   // preHist_.H0_ of e: one contiguous read
+#pragma unroll
+  for (int ip = 0; ip < NIP; ip++) H0v[ip] = 0.0;
+  if constexpr (PF) {
+    if (P.model == 1) {
+#pragma unroll
+      for (int ip = 0; ip < NIP; ip++) H0v[ip] = P.hist_pre[e * NIP + ip];
+    }
+  }
+  ElemData<SH, PF> E;
+  gather_elem<SH, PF>(P, cn, E);
+  R.zero();
+#pragma unroll 1
+  for (int ip = 0; ip < NIP; ip++) {
+    IpRec<SH, PF, KEEP> r;
+    double H0 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NIP; k++) if (k == ip) H0 = H0v[k];
+    ip_point<SH, FAM, WANT_K, KEEP>(P, e, ip, E, H0, owned && ((ip % NPE) == la), r, err_acc);
+    double Nip[NPE];
+#pragma unroll
+    for (int b = 0; b < NPE; b++) Nip[b] = P.tab[ip * NPE + b];
+    accum_rows<SH, FAM, WANT_K, KEEP>(P, r, la, Nip, R);
+  }
+}
+
+// ---- group broadcast: value of lane J of the NPE-lane group ----
+template <int NPE, int J>
+__device__ __forceinline__ double gbcast(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  if constexpr (NPE == 4) {                          // DPP quad_perm [J,J,J,J]
+    lo = __builtin_amdgcn_update_dpp(0, lo, J * 0x55, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, J * 0x55, 0xF, 0xF, false);
+  } else {
+    const int src = (((int)threadIdx.x & 63) & ~(NPE - 1)) + J;
+    lo = __builtin_amdgcn_ds_bpermute(src << 2, lo);
+    hi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
+  }
+  return __hiloint2double(hi, lo);
+}
+
+template <class SH, bool PF, bool KEEP, int J>
+__device__ __forceinline__ void bcast_rec(const IpRec<SH, PF, KEEP>& m, IpRec<SH, PF, KEEP>& r) {
+  constexpr int NPE = SH::NPE;
+  r.w = gbcast<NPE, J>(m.w);
+#pragma unroll
+  for (int a = 0; a < NPE; a++)
+#pragma unroll
+    for (int i = 0; i < SH::RANK; i++) r.g[a][i] = gbcast<NPE, J>(m.g[a][i]);
+  r.d0 = gbcast<NPE, J>(m.d0); r.d1 = gbcast<NPE, J>(m.d1); r.d3 = gbcast<NPE, J>(m.d3);
+#pragma unroll
+  for (int c = 0; c < SH::S; c++) r.sig[c] = gbcast<NPE, J>(m.sig[c]);
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int c = 0; c < SH::S; c++) r.sp[c] = gbcast<NPE, J>(m.sp[c]);
+    r.dg = gbcast<NPE, J>(m.dg); r.dgl = gbcast<NPE, J>(m.dgl);
+  }
+  if constexpr (PF) {
+    r.c1 = gbcast<NPE, J>(m.c1); r.cf = gbcast<NPE, J>(m.cf);
+#pragma unroll
+    for (int i = 0; i < SH::RANK; i++) r.gphi[i] = gbcast<NPE, J>(m.gphi[i]);
+  }
+}
+
+// Gauss-point loop of element e shared by its NPE lanes (NIP == NPE): lane la evaluates point la (phase 1),
+// then every lane accumulates the rows of its node from the NPE broadcast records (phase 2).
+// Every lane of the group must be active (DPP / bpermute read the other lanes' registers).
+template <class SH, int FAM, bool WANT_K, bool KEEP>
+__device__ __forceinline__ void shared_phase2(const Params& P, int la, const IpRec<SH, FAM != FAM_LE, KEEP>& mine,
+                                              RowBlock<SH, WANT_K, FAM != FAM_LE, KEEP>& R) {
+  constexpr int NPE = SH::NPE, NIP = SH::NIP;
+  constexpr bool PF = (FAM != FAM_LE);
+  static_assert(NIP == NPE, "shared evaluation needs one Gauss point per lane");
+  R.zero();
+  auto body = [&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    IpRec<SH, PF, KEEP> r;
+    bcast_rec<SH, PF, KEEP, J>(mine, r);
+    double Nip[NPE];
+#pragma unroll
+    for (int b = 0; b < NPE; b++) Nip[b] = P.tab[J * NPE + b];
+    accum_rows<SH, FAM, WANT_K, KEEP>(P, r, la, Nip, R);
+    __builtin_amdgcn_sched_barrier(0);               // keep the broadcast+accumulate rounds apart (registers)
+  };
+  SFor<0, NIP>::run(body);
+}
+
+// add one lane's row block into the LDS image of its node's CSR rows.  rs0 = LDS offset of the node's first
+// row, nnb = number of neighbour nodes of the node (row i has nnb*cnt[i] entries), ps[b] = position of
+// element node b in the node's neighbour list.
+template <class SH, bool WANT_K, bool PF, bool KEEP, bool ATOMIC>
+__device__ __forceinline__ void lds_add_rows(const Params& P, const RowBlock<SH, WANT_K, PF, KEEP>& R,
+                                             double* sK, double* sF, int rs0, int nnb, int fo,
+                                             const uint8_t (&ps)[SH::NPE]) {
+  constexpr int RANK = SH::RANK, NPE = SH::NPE;
+  auto add = [](double& ref, double v) {
+    if constexpr (ATOMIC) __hip_atomic_fetch_add(&ref, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else ref += v;
+  };
+#pragma unroll
+  for (int i = 0; i < RANK; i++) add(sF[fo + i], R.fu[i]);
+  if constexpr (PF) add(sF[fo + RANK], R.fp);
+  if constexpr (WANT_K) {
+    int rs = rs0;
+#pragma unroll
+    for (int i = 0; i < RANK; i++) {
+#pragma unroll
+      for (int b = 0; b < NPE; b++) {
+        const int gs = rs + (int)ps[b] * P.cnt[i];
+#pragma unroll
+        for (int j = 0; j < RANK; j++) add(sK[gs + P.off[i][j]], R.Kuu[i][b * RANK + j]);
+        if constexpr (KEEP) { if (P.keep2) add(sK[gs + P.off[i][RANK]], R.Kup[i][b]); }
+      }
+      rs += nnb * P.cnt[i];
+    }
+    if constexpr (PF) {
+#pragma unroll
+      for (int b = 0; b < NPE; b++) {
+        const int gs = rs + (int)ps[b] * P.cnt[RANK];
+        add(sK[gs + P.off[RANK][RANK]], R.Kpp[b]);
+        if constexpr (KEEP) {
+          if (P.keep3) {
+#pragma unroll
+            for (int j = 0; j < RANK; j++) add(sK[gs + P.off[RANK][j]], R.Kpu[b * RANK + j]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BLOCKSZ>
+__device__ __forceinline__ void reduce_err(double err_acc, double* sErr, double* out) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) err_acc += __shfl_down(err_acc, o, 64);
+  if ((threadIdx.x & 63) == 0) sErr[threadIdx.x >> 6] = err_acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int k = 0; k < (BLOCKSZ + 63) / 64; k++) s += sErr[k];
+    *out = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Patch kernel (default)
+// ------------------------------------------------------------------------------------------------
+// indices of one (patch element, lane): fetched one pass ahead of their use
+template <int NPE>
+struct LaneIdx {
+  int64_t e; int own; int32_t cn[NPE]; uint8_t ps[NPE];
+};
+
+template <int NPE>
+__device__ __forceinline__ void load_idx(const Params& P, int64_t recno, int la, bool valid, LaneIdx<NPE>& L) {
+  constexpr int RS = prec_stride(NPE), OW = prec_own_words(NPE), PW = prec_pos_words(NPE);
+  const int32_t* __restrict__ rec = P.prec + recno * RS;
+  L.e = rec[0];
+#pragma unroll
+  for (int b = 0; b < NPE; b++) L.cn[b] = rec[1 + b];
+  const uint32_t ow = (uint32_t)rec[1 + NPE + (la >> 1)];
+  L.own = valid ? (int)((la & 1) ? (ow >> 16) : (ow & 0xFFFFu)) : 0xFFFF;
+#pragma unroll
+  for (int w = 0; w < PW; w++) {
+    const uint32_t pw = (uint32_t)rec[1 + NPE + OW + la * PW + w];
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (w * 4 + q < NPE) L.ps[w * 4 + q] = (uint8_t)(pw >> (8 * q));
+  }
+}
+
+template <class SH, int FAM, bool WANT_K, bool KEEP>
+__global__ __launch_bounds__(SH::PBLOCK) void assemble_patch(const Params P) {
+  constexpr int RANK = SH::RANK, NPE = SH::NPE, BLK = SH::PBLOCK, GPB = BLK / NPE;   // element groups per pass
+  constexpr bool PF = (FAM != FAM_LE);
+  constexpr int NDOF = PF ? RANK + 1 : RANK;
+  extern __shared__ double smem[];
+  __shared__ double sErr[(BLK + 63) / 64];
+  double* sK = smem;                                         // [plds]            LDS image of the CSR rows
+  double* sF = smem + (WANT_K ? P.plds : 0);                 // [kMaxOwn * NDOF]  f_int of the owned nodes
+  int64_t* sG = (int64_t*)(sF + kMaxOwn * NDOF);             // [kMaxOwn]         first CSR entry of each node
+  int* sOff = (int*)(sG + kMaxOwn);                          // [kMaxOwn + 1]     LDS offset of each node's row block
+  int* sNode = sOff + (kMaxOwn + 1);                         // [kMaxOwn]         global node id
+  int* sNnb = sNode + kMaxOwn;                               // [kMaxOwn]         neighbour count
+  int* sRun = sNnb + kMaxOwn;                                // [kMaxOwn]         runs of consecutive node ids
+
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x;
+  const int nb0 = P.pn_ptr[p], nown = P.pn_ptr[p + 1] - nb0;
+  const int eb0 = P.pe_ptr[p], nelem = P.pe_ptr[p + 1] - eb0;
+  const int la = tid % NPE, grp = tid / NPE;
+
+  // software pipeline over the passes: indices two passes ahead, nodal gathers one pass ahead, so a wave
+  // never waits a full memory latency between two Gauss-point blocks even at 1-2 waves per SIMD
+  LaneIdx<NPE> cur, nxt;
+  load_idx<NPE>(P, (int64_t)eb0 + min(grp, nelem - 1), la, grp < nelem, cur);
+  nxt = cur;
+  if (GPB < nelem) load_idx<NPE>(P, (int64_t)eb0 + min(GPB + grp, nelem - 1), la, GPB + grp < nelem, nxt);
+  ElemData<SH, PF> E;
+  double H0 = 0.0;
+  gather_elem<SH, PF>(P, cur.cn, E);
+  if constexpr (PF) { if (P.model == 1) H0 = P.hist_pre[cur.e * SH::NIP + (SH::SHARE ? la : 0)]; }
+
+  int cntsum = 0;
+#pragma unroll
+  for (int i = 0; i < NDOF; i++) cntsum += P.cnt[i];
+  const int r0 = P.pr_ptr[p], nrun = P.pr_ptr[p + 1] - r0;
+  for (int j = tid; j < nrun; j += BLK) sRun[j] = P.prun[r0 + j];
+  for (int j = tid; j <= nown; j += BLK) {
+    sOff[j] = P.poff[nb0 + p + j];                           // nown+1 offsets per patch
+    if (j < nown) {
+      const int node = P.pnode[nb0 + j];
+      sNode[j] = node;
+      if constexpr (WANT_K) sG[j] = P.row_ptr[(int64_t)node * NDOF];
+    }
+  }
+  __syncthreads();
+  const int ldslen = sOff[nown];
+  for (int j = tid; j < nown; j += BLK) sNnb[j] = (sOff[j + 1] - sOff[j]) / cntsum;
+  if constexpr (WANT_K)
+    for (int i = tid; i < ldslen; i += BLK) sK[i] = 0.0;
+  for (int i = tid; i < nown * NDOF; i += BLK) sF[i] = 0.0;
+  __syncthreads();
+
+  double err_acc = 0.0;
+  for (int kb = 0; kb < nelem; kb += GPB) {
+    const bool owned = cur.own != 0xFFFF;                    // idle groups redo the last element, write nothing
+    const bool more = kb + GPB < nelem;
+    RowBlock<SH, WANT_K, PF, KEEP> R;
+    if constexpr (SH::SHARE) {
+      IpRec<SH, PF, KEEP> mine;
+      ip_point<SH, FAM, WANT_K, KEEP>(P, cur.e, la, E, H0, owned, mine, err_acc);
+      const LaneIdx<NPE> me = cur;
+      if (more) {                                            // gathers of the next pass fly during phase 2
+        cur = nxt;
+        gather_elem<SH, PF>(P, cur.cn, E);
+        if constexpr (PF) { if (P.model == 1) H0 = P.hist_pre[cur.e * SH::NIP + la]; }
+        const int k2 = kb + 2 * GPB + grp;
+        if (kb + 2 * GPB < nelem) load_idx<NPE>(P, (int64_t)eb0 + min(k2, nelem - 1), la, k2 < nelem, nxt);
+      }
+      shared_phase2<SH, FAM, WANT_K, KEEP>(P, la, mine, R);
+      if (me.own != 0xFFFF)
+        lds_add_rows<SH, WANT_K, PF, KEEP, true>(P, R, sK, sF, sOff[me.own], sNnb[me.own], me.own * NDOF, me.ps);
+    } else {
+      if (owned) {
+        compute_rowblock<SH, FAM, WANT_K, KEEP>(P, cur.e, la, cur.cn, true, R, err_acc);
+        lds_add_rows<SH, WANT_K, PF, KEEP, true>(P, R, sK, sF, sOff[cur.own], sNnb[cur.own], cur.own * NDOF, cur.ps);
+      }
+      if (more) {
+        cur = nxt;
+        const int k2 = kb + 2 * GPB + grp;
+        if (kb + 2 * GPB < nelem) load_idx<NPE>(P, (int64_t)eb0 + min(k2, nelem - 1), la, k2 < nelem, nxt);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- stream the finished rows out: runs of consecutive node ids are contiguous in the CSR value array ----
+  for (int rr = 0; rr < nrun; rr++) {
+    const int run = sRun[rr];
+    const int j0 = run & 0xFFFF, cnt = run >> 16;
+#if defined(FA_ABLATE) && (FA_ABLATE & 1)
+    if (cnt < 0)
+#endif
+    if constexpr (WANT_K) {
+      const int lo = sOff[j0], len = sOff[j0 + cnt] - lo;
+      double* __restrict__ Kg = P.K + sG[j0];
+      if (P.overwrite) for (int i = tid; i < len; i += BLK) Kg[i] = sK[lo + i];
+      else             for (int i = tid; i < len; i += BLK) Kg[i] += sK[lo + i];
+    }
+    double* __restrict__ fg = P.f + (int64_t)sNode[j0] * NDOF;
+    if (P.overwrite) for (int i = tid; i < cnt * NDOF; i += BLK) fg[i] = sF[j0 * NDOF + i];
+    else             for (int i = tid; i < cnt * NDOF; i += BLK) fg[i] += sF[j0 * NDOF + i];
+  }
+  if (PF && P.err_part != nullptr) reduce_err<BLK>(err_acc, sErr, &P.err_part[blockIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-gather kernel on contiguous node ranges, deterministic summation order (FA_DETERMINISTIC)
+// ------------------------------------------------------------------------------------------------
+template <class SH, int FAM, bool WANT_K, bool KEEP, bool ORDERED>
+__global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, kBlock = SH::BLOCK, kLdsDoubles = SH::LDS;
   constexpr bool PF = (FAM != FAM_LE);
   constexpr int NDOF = PF ? RANK + 1 : RANK;
@@ -424,9 +757,8 @@ __global__ __launch_bounds__(SH::BLOCK, SH::MIN_WAVES) void assemble_rows(const 
   const bool active = t < t1;
   RowBlock<SH, WANT_K, PF, KEEP> R;
   int32_t cn[NPE];
-  int la = 0, slot = -1, a = n0;
+  int la = 0, slot = -1, a = n0, rs0 = 0, nnb = 0;
   int64_t e = 0;
-  int rs[NDOF];
   uint8_t ps[NPE];
   double err_acc = 0.0;
   if (active) {
@@ -437,86 +769,30 @@ __global__ __launch_bounds__(SH::BLOCK, SH::MIN_WAVES) void assemble_rows(const 
 #pragma unroll
     for (int b = 0; b < NPE; b++) if (b == la) a = cn[b];
     slot = t - P.n2e_ptr[a];
-    if constexpr (WANT_K) {                        // row starts / column positions: issued before the compute
-#pragma unroll
-      for (int i = 0; i < NDOF; i++) rs[i] = (int)(P.row_ptr[(int64_t)a * NDOF + i] - base);
+    if constexpr (WANT_K) {                        // row start / column positions: issued before the compute
+      const int64_t r0 = P.row_ptr[(int64_t)a * NDOF], r1 = P.row_ptr[(int64_t)a * NDOF + 1];
+      rs0 = (int)(r0 - base); nnb = (int)(r1 - r0) / P.cnt[0];
 #pragma unroll
       for (int b = 0; b < NPE; b++) ps[b] = P.pos[(e * NPE + la) * NPE + b];
     }
-#if defined(FA_ABLATE) && (FA_ABLATE & 2)
-    {   // experiment: gathers only, no Gauss-point arithmetic
-      double acc = 0.0;
-      for (int b = 0; b < NPE; b++) { acc += P.coords[(int64_t)cn[b] * RANK] + P.coords[(int64_t)cn[b] * RANK + 1];
-        for (int i = 0; i < NDOF; i++) acc += P.state[(int64_t)cn[b] * NDOF + i]; }
-      for (int ip = 0; ip < SH::NIP; ip++) acc += P.hist_pre[e * SH::NIP + ip];
-      for (int i = 0; i < RANK; i++) R.fu[i] = acc; R.fp = acc;
-      if constexpr (WANT_K) { for (int i = 0; i < RANK; i++) for (int j = 0; j < SH::ND; j++) R.Kuu[i][j] = acc + j;
-        if constexpr (PF) for (int b = 0; b < NPE; b++) R.Kpp[b] = acc - b; }
-    }
-#else
-    compute_rowblock<SH, FAM, WANT_K, KEEP>(P, e, la, cn, R, err_acc);
-#endif
+    compute_rowblock<SH, FAM, WANT_K, KEEP>(P, e, la, cn, true, R, err_acc);
   }
   __syncthreads();
 
-  // ---- phased, conflict-free accumulation into the LDS image of the CSR rows ----
-#ifdef FA_LDS_ATOMIC
-#define FA_LDS_ADD(ref, v) __hip_atomic_fetch_add(&(ref), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#else
-#define FA_LDS_ADD(ref, v) (ref) += (v)
-#endif
-#if defined(FA_ABLATE) && (FA_ABLATE & 4)
-  if (active) { asm volatile("" :: "v"(R.fu[0]), "v"(R.fp)); if constexpr (WANT_K) { for (int j = 0; j < SH::ND; j++) asm volatile("" :: "v"(R.Kuu[0][j]), "v"(R.Kuu[1][j])); if constexpr (PF) for (int b = 0; b < NPE; b++) asm volatile("" :: "v"(R.Kpp[b])); } }
-  for (int s = 0; s < 0; s++) {
-#else
-#ifdef FA_LDS_ATOMIC
-  for (int s = 0; s < 1; s++) {
-#else
-  for (int s = 0; s < P.max_valence; s++) {
-#endif
-#endif
-#ifdef FA_LDS_ATOMIC
-    if (active) {
-#else
-    if (active && slot == s) {
-#endif
-      const int fo = (a - n0) * NDOF;
-#pragma unroll
-      for (int i = 0; i < RANK; i++) FA_LDS_ADD(sF[fo + i], R.fu[i]);
-      if constexpr (PF) FA_LDS_ADD(sF[fo + RANK], R.fp);
-      if constexpr (WANT_K) {
-#pragma unroll
-        for (int i = 0; i < RANK; i++) {
-#pragma unroll
-          for (int b = 0; b < NPE; b++) {
-            const int gs = rs[i] + (int)ps[b] * P.cnt[i];
-#pragma unroll
-            for (int j = 0; j < RANK; j++) FA_LDS_ADD(sK[gs + P.off[i][j]], R.Kuu[i][b * RANK + j]);
-            if constexpr (KEEP) { if (P.keep2) FA_LDS_ADD(sK[gs + P.off[i][RANK]], R.Kup[i][b]); }
-          }
-        }
-        if constexpr (PF) {
-#pragma unroll
-          for (int b = 0; b < NPE; b++) {
-            const int gs = rs[RANK] + (int)ps[b] * P.cnt[RANK];
-            FA_LDS_ADD(sK[gs + P.off[RANK][RANK]], R.Kpp[b]);
-            if constexpr (KEEP) {
-              if (P.keep3) {
-#pragma unroll
-                for (int j = 0; j < RANK; j++) FA_LDS_ADD(sK[gs + P.off[RANK][j]], R.Kpu[b * RANK + j]);
-              }
-            }
-          }
-        }
-      }
+  if constexpr (ORDERED) {
+    // phased accumulation: two lanes of one phase never share a node => no atomics, and every CSR entry is
+    // summed in ascending element order exactly like the reference's serial element loop
+    for (int s = 0; s < P.max_valence; s++) {
+      if (active && slot == s)
+        lds_add_rows<SH, WANT_K, PF, KEEP, false>(P, R, sK, sF, rs0, nnb, (a - n0) * NDOF, ps);
+      __syncthreads();
     }
+  } else {
+    // one pass of ds_add_f64: the (at most valence) addends of an entry arrive in any order
+    if (active) lds_add_rows<SH, WANT_K, PF, KEEP, true>(P, R, sK, sF, rs0, nnb, (a - n0) * NDOF, ps);
     __syncthreads();
   }
 
-  // ---- stream the finished rows out, coalesced ----
-#if defined(FA_ABLATE) && (FA_ABLATE & 1)
-  if (len < 0)
-#endif
   if constexpr (WANT_K) {
     double* __restrict__ Kg = P.K + base;
     if (P.overwrite) for (int i = tid; i < len; i += kBlock) Kg[i] = sK[i];
@@ -527,18 +803,7 @@ __global__ __launch_bounds__(SH::BLOCK, SH::MIN_WAVES) void assemble_rows(const 
     if (P.overwrite) for (int i = tid; i < nf; i += kBlock) fg[i] = sF[i];
     else             for (int i = tid; i < nf; i += kBlock) fg[i] += sF[i];
   }
-
-  if (PF && P.err_part != nullptr) {               // ExtIt: errExt_ partial of this workgroup
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) err_acc += __shfl_down(err_acc, o, 64);
-    if ((tid & 63) == 0) sErr[tid >> 6] = err_acc;
-    __syncthreads();
-    if (tid == 0) {
-      double s = 0.0;
-      for (int k = 0; k < kBlock / 64; k++) s += sErr[k];
-      P.err_part[blockIdx.x] = s;
-    }
-  }
+  if (PF && P.err_part != nullptr) reduce_err<kBlock>(err_acc, sErr, &P.err_part[blockIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -571,7 +836,7 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_generic(const Params P) {
 #pragma unroll
     for (int b = 0; b < NPE; b++) cn[b] = P.conn[e * NPE + b];
     RowBlock<SH, WANT_K, PF, KEEP> R;
-    compute_rowblock<SH, FAM, WANT_K, KEEP>(P, e, la, cn, R, err_acc);
+    compute_rowblock<SH, FAM, WANT_K, KEEP>(P, e, la, cn, true, R, err_acc);
     auto dof = [&](int node, int i) -> int64_t {
       return P.node_dofs ? P.node_dofs[(int64_t)node * NDOF + i] : (int64_t)node * NDOF + i;
     };
@@ -586,20 +851,20 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_generic(const Params P) {
         for (int i = 0; i < RANK; i++) {
           const int64_t row = dof(a, i);
           for (int j = 0; j < RANK; j++) {
-            const int64_t p = find_col(P, row, dof(cn[b], j));
-            if (p >= 0) atomicAdd(&P.K[p], R.Kuu[i][b * RANK + j]);
+            const int64_t q = find_col(P, row, dof(cn[b], j));
+            if (q >= 0) atomicAdd(&P.K[q], R.Kuu[i][b * RANK + j]);
           }
           if constexpr (KEEP) {
             if (P.keep2) {
-              const int64_t p = find_col(P, row, dof(cn[b], RANK));
-              if (p >= 0) atomicAdd(&P.K[p], R.Kup[i][b]);
+              const int64_t q = find_col(P, row, dof(cn[b], RANK));
+              if (q >= 0) atomicAdd(&P.K[q], R.Kup[i][b]);
             }
           }
         }
         if constexpr (PF) {
           const int64_t row = dof(a, RANK);
-          const int64_t p = find_col(P, row, dof(cn[b], RANK));
-          if (p >= 0) atomicAdd(&P.K[p], R.Kpp[b]);
+          const int64_t q0 = find_col(P, row, dof(cn[b], RANK));
+          if (q0 >= 0) atomicAdd(&P.K[q0], R.Kpp[b]);
           if constexpr (KEEP) {
             if (P.keep3) {
               for (int j = 0; j < RANK; j++) {
@@ -612,37 +877,42 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_generic(const Params P) {
       }
     }
   }
-  if (PF && P.err_part != nullptr) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) err_acc += __shfl_down(err_acc, o, 64);
-    if ((tid & 63) == 0) sErr[tid >> 6] = err_acc;
-    __syncthreads();
-    if (tid == 0) {
-      double s = 0.0;
-      for (int k = 0; k < kBlock / 64; k++) s += sErr[k];
-      P.err_part[blockIdx.x] = s;
-    }
-  }
+  if (PF && P.err_part != nullptr) reduce_err<kBlock>(err_acc, sErr, &P.err_part[blockIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
 template <class SH, int FAM, bool WANT_K, bool KEEP>
-static int launch_one(const Params& P, bool rows, int grid, hipStream_t st) {
-  if (rows) hipLaunchKernelGGL((assemble_rows<SH, FAM, WANT_K, KEEP>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
-  else      hipLaunchKernelGGL((assemble_generic<SH, FAM, WANT_K, KEEP>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
+static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
+  if (path == PATH_PATCH) {
+    auto kern = assemble_patch<SH, FAM, WANT_K, KEEP>;
+    const size_t shmem = patch_shmem_bytes(WANT_K ? P.plds : 0, (FAM != FAM_LE) ? SH::RANK + 1 : SH::RANK);
+    static size_t configured = 0;                  // per instantiation
+    if (shmem > 65536 && shmem > configured) {
+      hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (rc != hipSuccess) return (int)rc;
+      configured = shmem;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SH::PBLOCK), shmem, st, P);
+  } else if (path == PATH_ROWS) {
+    hipLaunchKernelGGL((assemble_rows<SH, FAM, WANT_K, KEEP, false>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
+  } else if (path == PATH_ROWS_ORDERED) {
+    hipLaunchKernelGGL((assemble_rows<SH, FAM, WANT_K, KEEP, true>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
+  } else {
+    hipLaunchKernelGGL((assemble_generic<SH, FAM, WANT_K, KEEP>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
+  }
   return (int)hipGetLastError();
 }
 
 template <class SH>
-static int launch_shape(const Params& P, int fam, bool want_K, bool keep, bool rows, int grid, void* stream) {
+static int launch_shape(const Params& P, int fam, bool want_K, bool keep, int path, int grid, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (fam == FAM_LE)
-    return want_K ? launch_one<SH, FAM_LE, true, false>(P, rows, grid, st)
-                  : launch_one<SH, FAM_LE, false, false>(P, rows, grid, st);
+    return want_K ? launch_one<SH, FAM_LE, true, false>(P, path, grid, st)
+                  : launch_one<SH, FAM_LE, false, false>(P, path, grid, st);
   if (fam == FAM_PF_ISO) {
-    if (!want_K) return launch_one<SH, FAM_PF_ISO, false, false>(P, rows, grid, st);
-    return keep ? launch_one<SH, FAM_PF_ISO, true, true>(P, rows, grid, st)
-                : launch_one<SH, FAM_PF_ISO, true, false>(P, rows, grid, st);
+    if (!want_K) return launch_one<SH, FAM_PF_ISO, false, false>(P, path, grid, st);
+    return keep ? launch_one<SH, FAM_PF_ISO, true, true>(P, path, grid, st)
+                : launch_one<SH, FAM_PF_ISO, true, false>(P, path, grid, st);
   }
   return -1000;   // family not built for this shape
 }

@@ -2,7 +2,7 @@
 #include "fa_kernel_impl.h"
 
 namespace fa {
-int launch_hex8_g2(const Params& P, int fam, bool want_K, bool keep, bool rows, int grid, void* stream) {
-  return launch_shape<Shape<3,8,8>>(P, fam, want_K, keep, rows, grid, stream);
+int launch_hex8_g2(const Params& P, int fam, bool want_K, bool keep, int path, int grid, void* stream) {
+  return launch_shape<Shape<3,8,8>>(P, fam, want_K, keep, path, grid, stream);
 }
 }  // namespace fa

@@ -2,7 +2,7 @@
 #include "fa_kernel_impl.h"
 
 namespace fa {
-int launch_quad4_g2(const Params& P, int fam, bool want_K, bool keep, bool rows, int grid, void* stream) {
-  return launch_shape<Shape<2,4,4>>(P, fam, want_K, keep, rows, grid, stream);
+int launch_quad4_g2(const Params& P, int fam, bool want_K, bool keep, int path, int grid, void* stream) {
+  return launch_shape<Shape<2,4,4>>(P, fam, want_K, keep, path, grid, stream);
 }
 }  // namespace fa

@@ -2,7 +2,7 @@
 #include "fa_kernel_impl.h"
 
 namespace fa {
-int launch_tri3_g1(const Params& P, int fam, bool want_K, bool keep, bool rows, int grid, void* stream) {
-  return launch_shape<Shape<2,3,1>>(P, fam, want_K, keep, rows, grid, stream);
+int launch_tri3_g1(const Params& P, int fam, bool want_K, bool keep, int path, int grid, void* stream) {
+  return launch_shape<Shape<2,3,1>>(P, fam, want_K, keep, path, grid, stream);
 }
 }  // namespace fa

@@ -54,7 +54,9 @@ enum {
                            PhaseFractureModel.cpp:738-749); the caller zeroes beforehand */
   FA_OVERWRITE    = 1,  /* K = , f = over the whole pattern (== caller's zero-fill followed by +=) */
   FA_STORE_STRAIN = 2,  /* also materialise the strain_ cache (PhaseFractureModel.cpp:651,678) */
-  FA_FORCE_GENERIC = 4  /* testing: use the generic atomic-scatter kernel even for a canonical pattern */
+  FA_FORCE_GENERIC = 4, /* testing: use the generic atomic-scatter kernel even for a canonical pattern */
+  FA_DETERMINISTIC = 8  /* bitwise run-to-run reproducible K/f: every entry summed in ascending element order
+                           (slower row kernel instead of the patch kernel) */
 };
 
 typedef struct {
@@ -106,8 +108,11 @@ int64_t   fa_nnz(const fa_ctx* ctx);
 int64_t   fa_nip_total(const fa_ctx* ctx);
 int32_t   fa_ndof_per_node(const fa_ctx* ctx);
 int32_t   fa_strain_rows(const fa_ctx* ctx);
-/* 1 if the coalesced row-gather kernel is used, 0 if the generic atomic-scatter kernel is */
+/* 1 if the coalesced LDS-staged kernels (patch / row) are used, 0 if the generic atomic-scatter kernel is */
 int32_t   fa_uses_row_kernel(const fa_ctx* ctx);
+/* set-up statistics of the patch kernel: number of node patches and Gauss-point redundancy
+ * (element evaluations / elements; halo elements are evaluated by every patch they touch).  No reference counterpart. */
+int32_t   fa_patch_stats(const fa_ctx* ctx, double* redundancy);
 /* Psi0_ (PhaseFractureModel.cpp:296-355) */
 double    fa_psi0(const fa_ctx* ctx);
 

@@ -116,6 +116,41 @@ def test_written_pattern_accumulate_shuffled(shape):
 
 
 @pytest.mark.parametrize("shape", [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2])
+@pytest.mark.parametrize("flags", [capi.OVERWRITE, capi.ACCUMULATE])
+def test_deterministic_row_kernel(shape, flags):
+    """FA_DETERMINISTIC: phased row kernel, every entry summed in ascending element order."""
+    run_both(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, keep=1, flags=flags | capi.DETERMINISTIC)
+    run_both(shape, capi.PHASE_FRACTURE_EXTIT, capi.BOURDIN_PHASE, flags=flags | capi.DETERMINISTIC, shuffle=True)
+    run_both(shape, capi.LINEAR_ELASTICITY, capi.HOOKE, flags=flags | capi.DETERMINISTIC)
+
+
+@pytest.mark.parametrize("use_patch", [False, True])
+def test_many_workgroups(use_patch, monkeypatch):
+    """A mesh large enough for hundreds of workgroups with ragged boundaries (shuffled numbering); also the
+    opt-in experimental patch kernel (FA_USE_PATCH)."""
+    if use_patch:
+        monkeypatch.setenv("FA_USE_PATCH", "1")
+    coords, conn = meshgen.grid_quad4(150, 131)
+    coords = meshgen.distort(coords, conn, 0.2, 3)
+    coords, conn, _ = meshgen.shuffle_nodes(coords, conn, 3)
+    kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.05, keep_off_diags=True)
+    asm = capi.Assembler(capi.QUAD4_G2, capi.PHASE_FRACTURE, capi.AMOR_PHASE, coords, conn, **kw)
+    if use_patch:
+        assert asm.npatch > 100 and 1.0 < asm.redundancy < 2.0
+    st = meshgen.smooth_state(coords, 3, l0=0.05)
+    cfg = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE, po.AMOR, **kw)
+    rp, ci = asm.pattern()
+    K, f, _ = asm.assemble_host(st, np.zeros(asm.nnz), flags=capi.OVERWRITE)
+    ref = po.assemble(cfg, coords, conn, rp, ci, st)
+    assert rel_rowmax_err(rp, K, ref["K"]) < TOL and vec_err(f, ref["f"]) < TOL
+    assert vec_err(asm.get_history(1), ref["hist_new"]) < TOL
+    K2, f2, _ = asm.assemble_host(st, np.zeros(asm.nnz), flags=capi.OVERWRITE | capi.DETERMINISTIC)
+    K3, f3, _ = asm.assemble_host(st, np.zeros(asm.nnz), flags=capi.OVERWRITE | capi.DETERMINISTIC)
+    assert np.array_equal(K2, K3) and np.array_equal(f2, f3)
+    assert rel_rowmax_err(rp, K2, ref["K"]) < TOL
+
+
+@pytest.mark.parametrize("shape", [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2])
 def test_force_only(shape):
     run_both(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, want_K=False)
     run_both(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, want_K=False, flags=capi.ACCUMULATE)
