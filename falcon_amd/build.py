@@ -48,7 +48,27 @@ def build(force=False, verbose=False):
                 print(err)
     if jobs or not os.path.exists(OUT):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    build_host(force or bool(jobs), verbose)
     return OUT
+
+
+HOST_OUT = os.path.join(HERE, "libfalcon_host.so")
+
+
+def build_host(force=False, verbose=False):
+    """The C++ host mirror of the reference's plugin interface (falcon_amd/host), on top of the C ABI."""
+    src = os.path.join(HERE, "host", "falcon_host.cpp")
+    deps = [src, os.path.join(HERE, "host", "falcon_host.h"), os.path.join(HERE, "..", "include", "falcon_assemble.h")]
+    if not force and _newer(HOST_OUT, deps):
+        return HOST_OUT
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_OUT, src,
+           "-L" + HERE, "-lfalcon_assemble", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed:\n" + r.stdout + r.stderr)
+    return HOST_OUT
 
 
 if __name__ == "__main__":

@@ -1,0 +1,119 @@
+"""The C++ host mirror of the reference's plugin interface (falcon_amd/host): same model names, property names,
+action strings and error behaviour as src/fem/solidmech/*Model.cpp, on top of the C ABI."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from falcon_amd import hostapi
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sm01")
+PRO = open(os.path.join(G, "model.pro")).read()
+MESH = open(os.path.join(G, "problem.mesh")).read()
+
+
+def _gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_errors_mirror_the_reference():
+    """Constructor-time errors come before any GPU call, with the reference's wording."""
+    with pytest.raises(hostapi.HostError, match="Invalid material: Steel"):
+        hostapi.Case(PRO.replace('"Hooke"', '"Steel"'), MESH)
+    with pytest.raises(hostapi.HostError, match="undefined element group"):
+        hostapi.Case(PRO.replace("DomainElems", "Nowhere"), MESH)
+    with pytest.raises(hostapi.HostError, match="shape has invalid rank: 3"):
+        hostapi.Case(PRO.replace('"Triangle3"', '"Hex8"').replace('"Gauss1"', '"Gauss2*Gauss2*Gauss2"'), MESH)
+    pf = PRO.replace('"LinearElasticity"', '"PhaseFracture"').replace('"Hooke"', '"AmorPhase"')
+    with pytest.raises(hostapi.HostError, match="fractureType"):
+        hostapi.Case(pf, MESH)
+    with pytest.raises(hostapi.HostError, match="unexpected definition of fracture type"):
+        hostapi.Case(pf.replace('elements = "DomainElems";', 'elements = "DomainElems"; fractureType = "at3";'), MESH)
+    with pytest.raises(hostapi.HostError, match="3 nodes"):
+        hostapi.Case(PRO.replace('"Triangle3"', '"Quad4"').replace('"Gauss1"', '"Gauss2*Gauss2"'), MESH)
+    if not _gpu():      # a valid case gets as far as fa_create and fails loudly there: no CPU fallback
+        with pytest.raises(hostapi.HostError, match="hip"):
+            hostapi.Case(PRO, MESH)
+
+
+@pytest.mark.gpu
+def test_sm01_through_take_action():
+    """BASELINE config 1: tests/sm01 as shipped, driven like Jive drives it (GET_MATRIX0 on a zeroed K / f)."""
+    exp = json.load(open(os.path.join(G, "expected.json")))
+    case = hostapi.Case(PRO, MESH)
+    assert case.model_type == "LinearElasticity" and case.ndof == 8 and case.nnz == 56
+    # dofs are node-major / type-minor in node order (XDofSpace::addDofs)
+    assert [case.dof(n, t) for n in (1, 2, 3, 4) for t in ("dx", "dy")] == list(range(8))
+    u = np.array(exp["u"])
+    handled, K, f = case.take_action("GET_MATRIX0", state=u)
+    assert handled
+    rp, ci = case.pattern()
+    Kd = np.zeros((8, 8))
+    for r in range(8):
+        Kd[r, ci[rp[r]:rp[r + 1]]] = K[rp[r]:rp[r + 1]]
+    assert np.abs(Kd - np.array(exp["K"])).max() < 1e-12 * np.abs(Kd).max()
+    assert np.abs(f - np.array(exp["f_int"])).max() < 1e-12 * np.abs(f).max()
+    top = [case.dof(3, "dy"), case.dof(4, "dy")]                       # Lodi: load[1] over TopNodes
+    assert abs(f[top].sum() - 1.0989010989010989) < 1e-13
+    # LinearElasticityModel answers neither GET_INT_VECTOR nor unknown actions (LinearElasticityModel.cpp:213-289)
+    assert case.take_action("GET_INT_VECTOR", state=u)[0] is False
+    assert case.take_action("ADVANCE")[0] is False
+    assert case.take_action("COMMIT")[0] is True and case.take_action("CHECK_COMMIT")[0] is True
+
+
+@pytest.mark.gpu
+def test_phase_fracture_models_through_take_action():
+    from falcon_amd import meshgen
+    from oracle import pyoracle as po
+    coords, conn = meshgen.grid_quad4(6, 5)
+    coords = meshgen.distort(coords, conn, 0.1)
+    mesh = "<Nodes>\n" + "".join(f"{i + 1} {x:.17g} {y:.17g};\n" for i, (x, y) in enumerate(coords)) + "</Nodes>\n"
+    mesh += "<Elements>\n" + "".join(f"{e + 1} " + " ".join(str(n + 1) for n in c) + ";\n" for e, c in enumerate(conn))
+    mesh += "</Elements>\n<ElementGroup name=\"all\">\n{" + ",".join(str(e + 1) for e in range(len(conn))) + "}\n</ElementGroup>\n"
+    pro = '''model = "Matrix" { matrix.type = "FEM"; model = "Multi" { models = ["bulk"];
+      bulk = "%s" { elements = "all"; shape = { type = "Quad4"; intScheme = "Gauss2*Gauss2"; };
+        material = { type = "AmorPhase"; rank = 2; state = "PLANE_STRAIN"; young = 210.0; poisson = 0.3; };
+        fractureType = "at2"; griffithEnergy = 2.7e-3; lengthScale = 0.2; keepOffDiags = true; penalty = 6500.; }; }; };'''
+    st = meshgen.smooth_state(coords, 3, amp=5e-3, noise=1e-4, l0=0.3)
+    nn = coords.shape[0]
+    kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2, keep_off_diags=1, beta=6500.0)
+    # PhaseFracture: GET_MATRIX0, COMMIT (history swap), GET_INT_VECTOR
+    case = hostapi.Case(pro % "PhaseFracture", mesh)
+    rp, ci = case.pattern()
+    rpo, cio = po.pattern(nn, conn, 3, 2)
+    assert np.array_equal(rp, rpo) and np.array_equal(ci, cio)
+    cfg = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE, po.AMOR, **kw)
+    ok, K, f = case.take_action("GET_MATRIX0", state=st)
+    r1 = po.assemble(cfg, coords, conn, rp, ci, st)
+    assert ok and np.abs(K - r1["K"]).max() < 1e-12 * np.abs(K).max() and np.abs(f - r1["f"]).max() < 1e-12 * np.abs(f).max()
+    assert case.take_action("COMMIT")[0]
+    st2 = st * 0.5
+    ok, _, f2 = case.take_action("GET_INT_VECTOR", state=st2)
+    r2 = po.assemble(cfg, coords, conn, rp, ci, st2, hist_pre=r1["hist_new"], want_K=False)
+    assert ok and np.abs(f2 - r2["f"]).max() < 1e-12 * np.abs(f2).max()
+    # PhaseFractureExt: setStepSize returns false but sets dt_ (sic), COMMIT copies dt_ to dt0_
+    case = hostapi.Case(pro % "PhaseFractureExt", mesh)
+    cfg = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE_EXT, po.AMOR, **kw)
+    st0 = st.copy(); st0[2::3] += 0.01
+    st00 = st.copy(); st00[2::3] -= 0.01
+    assert case.take_action("setStepSize", step=0.3, step0=9.9)[0] is False
+    assert case.take_action("COMMIT")[0]
+    assert case.take_action("setStepSize", step=0.5, step0=9.9)[0] is False
+    ok, K, f = case.take_action("GET_MATRIX0", state=st, state0=st0, state00=st00)
+    r = po.assemble(cfg, coords, conn, rp, ci, st, state0=st0, state00=st00, dt=0.5, dt0=0.3)
+    assert ok and np.abs(K - r["K"]).max() < 1e-12 * np.abs(K).max() and np.abs(f - r["f"]).max() < 1e-12 * np.abs(f).max()
+    # PhaseFractureExtIt: stateExt_ built at iteration 0, checkCommit relaxes it when errExt_ is large
+    case = hostapi.Case(pro % "PhaseFractureExtIt", mesh)
+    cfg = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE_EXTIT, po.AMOR, **kw)
+    case.take_action("setStepSize", step=0.5, step0=0.25)
+    ok, K, f = case.take_action("GET_MATRIX0", state=st, state0=st0, state00=st00, iter_count=0)
+    ext = st00 + (0.5 + 0.25) / (0.25 + 1e-15) * (st0 - st00)
+    r = po.assemble(cfg, coords, conn, rp, ci, st, state0=st0, state00=ext)
+    assert ok and np.abs(K - r["K"]).max() < 1e-12 * np.abs(K).max() and np.abs(f - r["f"]).max() < 1e-12 * np.abs(f).max()
+    assert r["err_ext"] > 1e-8
+    assert case.take_action("checkCommit", state=st)[0]                 # errExt_ > 1e-8 => stateExt_ relaxed, extFail_
+    ok, K, f = case.take_action("GET_MATRIX0", state=st, state0=st0, state00=st00, iter_count=0)
+    r = po.assemble(cfg, coords, conn, rp, ci, st, state0=st0, state00=0.25 * ext + 0.75 * st)
+    assert ok and np.abs(f - r["f"]).max() < 1e-12 * np.abs(f).max()
