@@ -194,9 +194,8 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   // material <-> model pairing (PhaseFractureModel.cpp:193-194 dynamicCast<PhaseFractureMaterial>)
   if (!pf && p->material != FA_HOOKE) return fail(FA_ERR_ARG, "LinearElasticity needs material Hooke");
   if (pf && p->material == FA_HOOKE) return fail(FA_ERR_ARG, "phase-field models need a PhaseFractureMaterial");
-  if (p->material == FA_MIEHE_PHASE) return fail(FA_ERR_UNSUPPORTED, "MiehePhase has no gfx950 kernel yet");
   if (p->material < FA_HOOKE || p->material > FA_MIEHE_PHASE) return fail(FA_ERR_ARG, "Invalid material: %d", p->material);
-  c->fam = !pf ? fa::FAM_LE : fa::FAM_PF_ISO;
+  c->fam = !pf ? fa::FAM_LE : (p->material == FA_MIEHE_PHASE ? fa::FAM_PF_MIEHE : fa::FAM_PF_ISO);
   if (sh.rank == 2 && p->state != FA_PLANE_STRAIN && p->state != FA_PLANE_STRESS)
     return fail(FA_ERR_ARG, "unexpected rank/state");     // HookeMaterial.cpp:262-265
   if (p->nnode <= 0 || p->nel < 0 || !p->coords || (!p->conn && p->nel)) return fail(FA_ERR_ARG, "empty mesh arrays");
@@ -391,7 +390,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   c->rows_path = rows_ok;
   // ---- node patches (patch kernel) ----
   fa::PatchSet ps;
-  if (rows_ok && nel > 0 && getenv("FA_USE_PATCH")) {               // experimental, opt-in
+  if (rows_ok && nel > 0 && c->fam != fa::FAM_PF_MIEHE && getenv("FA_USE_PATCH")) {               // experimental, opt-in
     int cap = (rank == 2) ? 6144 : 16384;                       // doubles of LDS for the CSR image
     if (const char* env = getenv("FA_PATCH_LDS")) cap = std::max(64, atoi(env));
     const size_t lim = 160 * 1024;

@@ -81,11 +81,13 @@ struct RowBlock {
 };
 
 // Everything the row accumulation needs from one Gauss point.
-template <class SH, bool PF, bool KEEP>
+template <class SH, int FAM, bool KEEP>
 struct IpRec {
+  static constexpr bool PF = (FAM != FAM_LE), GEN = (FAM == FAM_PF_MIEHE);
   double w;                          // w_ref * det J
   double g[SH::NPE][SH::RANK];       // dN_a/dx_i
   double d0, d1, d3;                 // tangent D in isotropic form
+  double D[GEN ? SH::S : 1][GEN ? SH::S : 1];   // general symmetric tangent (Miehe)
   double sig[SH::S];                 // stress
   double sp[KEEP ? SH::S : 1];       // sigma+ = dPsi/deps (off-diagonal blocks only)
   double c1, cf;                     // N N^T coefficient of K4; N coefficient of f2
@@ -195,6 +197,126 @@ __device__ __forceinline__ void iso_update(const Params& P, const double (&e)[S]
   }
 }
 
+// One Jacobi rotation in the (p,q) plane of the symmetric 3x3 matrix a, eigenvector columns accumulated in V
+// (same operation order as the checker's cyclic Jacobi so that both resolve near-degenerate strains alike).
+template <int p, int q, int N>
+__device__ __forceinline__ void jacobi_rot(double (&a)[3][3], double (&V)[3][3]) {
+  if (a[p][q] == 0.0) return;
+  const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+  const double t = ((theta >= 0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+  for (int k = 0; k < N; k++) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
+#pragma unroll
+  for (int k = 0; k < N; k++) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
+#pragma unroll
+  for (int k = 0; k < N; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+}
+
+// MiehePhaseMaterial::update + getposProj_ (MiehePhaseMaterial.cpp:200-258,342-406) in Voigt form.  With
+// M_a = n_a n_a^T and S_ab = n_a n_b^T + n_b n_a^T the projector of :378-404 is
+//   P+ = sum_a d_a M_a (x) M_a + sum_{b<a} theta_ab S_ab (x) S_ab         (G_ab + G_ba == S_ab (x) S_ab),
+// so tensor2voigt(P+) = sum d_a m_a m_a^T + sum theta_ab s_ab s_ab^T with the Voigt vectors of M_a, S_ab.
+// 2D: the strain tensor has no z entries; the z eigen-direction (eigenvalue 0, d = 0) only feeds zz / out-of-plane
+// shear entries, which B never touches, so the in-plane 2x2 problem is solved.
+template <int RANK, int S>
+__device__ __forceinline__ void miehe_update(const Params& P, const double (&e)[S], double g, double (&D)[S][S],
+                                             double (&sig)[S], double (&sp)[S], double& Psi) {
+  constexpr int N = RANK;
+  constexpr int VI[6] = { 0, 1, 2, 0, 1, 2 }, VJ[6] = { 0, 1, 2, 1, 2, 0 };   // 3D Voigt: xx yy zz xy yz zx
+  auto vi = [&](int I) { return (RANK == 2) ? (I == 2 ? 0 : I) : VI[I]; };
+  auto vj = [&](int I) { return (RANK == 2) ? (I == 2 ? 1 : I) : VJ[I]; };
+  double a[3][3], V[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { a[i][j] = 0.0; V[i][j] = (i == j) ? 1.0 : 0.0; }
+#pragma unroll
+  for (int I = 0; I < S; I++) {                        // voigt2tensorStrain: shear halved (TensorUtils.cpp:467-492)
+    const double v = (I < N) ? e[I] : 0.5 * e[I];
+    a[vi(I)][vj(I)] = v; a[vj(I)][vi(I)] = v;
+  }
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off, dia;
+    if constexpr (RANK == 2) { off = a[0][1] * a[0][1]; dia = a[0][0] * a[0][0] + a[1][1] * a[1][1]; }
+    else { off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+           dia = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2]; }
+    if (off <= 1e-300 || off <= 1e-34 * dia) break;
+    jacobi_rot<0, 1, N>(a, V);
+    if constexpr (RANK == 3) { jacobi_rot<0, 2, N>(a, V); jacobi_rot<1, 2, N>(a, V); }
+  }
+  double val[N], epos[N], dg[N];
+#pragma unroll
+  for (int r = 0; r < N; r++) { val[r] = a[r][r]; epos[r] = 0.5 * (val[r] + fabs(val[r])); dg[r] = (val[r] > 0.0) ? 1.0 : 0.0; }
+  double Pv[S][S];
+#pragma unroll
+  for (int I = 0; I < S; I++)
+#pragma unroll
+    for (int J = 0; J < S; J++) Pv[I][J] = 0.0;
+#pragma unroll
+  for (int r = 0; r < N; r++) {
+    double m[S];
+#pragma unroll
+    for (int I = 0; I < S; I++) m[I] = V[vi(I)][r] * V[vj(I)][r];
+#pragma unroll
+    for (int I = 0; I < S; I++)
+#pragma unroll
+      for (int J = I; J < S; J++) Pv[I][J] += (m[I] * m[J]) * dg[r];
+  }
+#pragma unroll
+  for (int r = 0; r < N; r++)
+#pragma unroll
+    for (int b = 0; b < r; b++) {
+      double th;
+      if (fabs(val[r] - val[b]) <= 1e-13) th = 0.5 * (dg[r] + dg[b]) / 2.0;
+      else                                th = 0.5 * (epos[r] - epos[b]) / (val[r] - val[b]);
+      double sv[S];
+#pragma unroll
+      for (int I = 0; I < S; I++) sv[I] = V[vi(I)][r] * V[vj(I)][b] + V[vi(I)][b] * V[vj(I)][r];
+#pragma unroll
+      for (int I = 0; I < S; I++)
+#pragma unroll
+        for (int J = I; J < S; J++) Pv[I][J] += th * (sv[I] * sv[J]);
+    }
+#pragma unroll
+  for (int I = 0; I < S; I++)
+#pragma unroll
+    for (int J = 0; J < I; J++) Pv[I][J] = Pv[J][I];
+  // strainPos = P+ : T (engineering shear carries the factor 2 of the kl / lk pair)
+  double spos[S];
+#pragma unroll
+  for (int I = 0; I < S; I++) {
+    double s = 0.0;
+#pragma unroll
+    for (int J = 0; J < S; J++) s += Pv[I][J] * e[J];
+    spos[I] = s;
+  }
+  double tr = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; i++) tr += e[i];
+  const double trP = 0.5 * (tr + fabs(tr)), trN = 0.5 * (tr - fabs(tr));
+  double dd = 0.0;
+#pragma unroll
+  for (int I = 0; I < S; I++) dd += ((I < N) ? 1.0 : 2.0) * (spos[I] * spos[I]);
+  Psi = 0.5 * P.lmda * (trP * trP) + P.G * dd;
+#pragma unroll
+  for (int I = 0; I < S; I++) {
+    const double T = (I < N) ? e[I] : 0.5 * e[I];
+    const double vP = ((I < N) ? P.lmda * trP : 0.0) + 2.0 * P.G * spos[I];
+    const double vN = ((I < N) ? P.lmda * trN : 0.0) + 2.0 * P.G * (T - spos[I]);
+    sp[I] = vP; sig[I] = g * vP + vN;
+  }
+  const double H = (tr < 0.0) ? 0.0 : 1.0;            // heavisideP(0) == 1 (MathUtils.cpp:33-36)
+#pragma unroll
+  for (int I = 0; I < S; I++)
+#pragma unroll
+    for (int J = 0; J < S; J++) {
+      const double I4 = (I == J) ? ((I < N) ? 1.0 : 0.5) : 0.0;
+      const double II = (I < N && J < N) ? 1.0 : 0.0;
+      D[I][J] = g * (2.0 * P.G * Pv[I][J] + P.lmda * H * II) + (2.0 * P.G * (I4 - Pv[I][J]) + P.lmda * (1.0 - H) * II);
+    }
+}
+
 // B_a^T v for a Voigt vector v (2D: xx,yy,xy; 3D: xx,yy,zz,xy,yz,zx), ShapeUtils.cpp:73-145
 template <int RANK, int S>
 __device__ __forceinline__ void Bt_vec(const double (&ga)[RANK], const double (&v)[S], double (&out)[RANK]) {
@@ -214,7 +336,7 @@ __device__ __forceinline__ void Bt_vec(const double (&ga)[RANK], const double (&
 // (history, strain cache, errExt_).
 template <class SH, int FAM, bool WANT_K, bool KEEP>
 __device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, const ElemData<SH, FAM != FAM_LE>& E,
-                                         double H0, bool write, IpRec<SH, FAM != FAM_LE, KEEP>& r, double& err_acc) {
+                                         double H0, bool write, IpRec<SH, FAM, KEEP>& r, double& err_acc) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, S = SH::S, STR = SH::STR;
   constexpr bool PF = (FAM != FAM_LE);
   const double* __restrict__ tabN = P.tab;
@@ -335,7 +457,8 @@ __device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, con
       degrade(P, pf, t3, dgphi, ddgphi);
     }
     if (P.strain != nullptr && write) P.strain[ipoint * srows + STR] = gmat;
-    iso_update<RANK, S>(P, eps, gmat, r.d0, r.d1, r.d3, r.sig, sp, Psi);
+    if constexpr (FAM == FAM_PF_MIEHE) { r.d0 = r.d1 = r.d3 = 0.0; miehe_update<RANK, S>(P, eps, gmat, r.D, r.sig, sp, Psi); }
+    else iso_update<RANK, S>(P, eps, gmat, r.d0, r.d1, r.d3, r.sig, sp, Psi);
     if (P.model == 1) {                                 // PhaseFractureModel.cpp:696-703
       if (Psi < H0) loading = 0.0;
       Psi = (Psi > H0) ? Psi : H0;
@@ -360,7 +483,7 @@ __device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, con
 
 // Rows of local node la from one Gauss-point record.  Nip[b] = N_b(ip).
 template <class SH, int FAM, bool WANT_K, bool KEEP>
-__device__ __forceinline__ void accum_rows(const Params& P, const IpRec<SH, FAM != FAM_LE, KEEP>& r, int la,
+__device__ __forceinline__ void accum_rows(const Params& P, const IpRec<SH, FAM, KEEP>& r, int la,
                                            const double (&Nip)[SH::NPE],
                                            RowBlock<SH, WANT_K, FAM != FAM_LE, KEEP>& R) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, S = SH::S;
@@ -381,7 +504,31 @@ __device__ __forceinline__ void accum_rows(const Params& P, const IpRec<SH, FAM 
 #pragma unroll
     for (int i = 0; i < RANK; i++) R.fu[i] += t[i];
   }
-  if constexpr (WANT_K) {
+  if constexpr (WANT_K && FAM == FAM_PF_MIEHE) {       // K1 += w B_a^T D B_b with a full symmetric D
+    double A[RANK][S];                                // A = w B_a^T D
+#pragma unroll
+    for (int c = 0; c < S; c++) {
+      double col[S], t[RANK];
+#pragma unroll
+      for (int k = 0; k < S; k++) col[k] = r.D[k][c];
+      Bt_vec<RANK, S>(wga, col, t);
+#pragma unroll
+      for (int i = 0; i < RANK; i++) A[i][c] = t[i];
+    }
+#pragma unroll
+    for (int b = 0; b < NPE; b++) {
+      double gb[RANK];
+#pragma unroll
+      for (int i = 0; i < RANK; i++) gb[i] = r.g[b][i];
+#pragma unroll
+      for (int i = 0; i < RANK; i++) {
+        double t[RANK];
+        Bt_vec<RANK, S>(gb, A[i], t);
+#pragma unroll
+        for (int j = 0; j < RANK; j++) R.Kuu[i][b * RANK + j] += t[j];
+      }
+    }
+  } else if constexpr (WANT_K) {
     if constexpr (RANK == 2) {                        // K1 += w B_a^T D B_b (:713)
       const double a00 = wga[0] * r.d0, a01 = wga[0] * r.d1, a03 = wga[0] * r.d3;
       const double a10 = wga[1] * r.d0, a11 = wga[1] * r.d1, a13 = wga[1] * r.d3;
@@ -469,7 +616,7 @@ __device__ __forceinline__ void compute_rowblock(const Params& P, int64_t e, int
   R.zero();
 #pragma unroll 1
   for (int ip = 0; ip < NIP; ip++) {
-    IpRec<SH, PF, KEEP> r;
+    IpRec<SH, FAM, KEEP> r;
     double H0 = 0.0;
 #pragma unroll
     for (int k = 0; k < NIP; k++) if (k == ip) H0 = H0v[k];
@@ -496,9 +643,11 @@ __device__ __forceinline__ double gbcast(double v) {
   return __hiloint2double(hi, lo);
 }
 
-template <class SH, bool PF, bool KEEP, int J>
-__device__ __forceinline__ void bcast_rec(const IpRec<SH, PF, KEEP>& m, IpRec<SH, PF, KEEP>& r) {
+template <class SH, int FAM, bool KEEP, int J>
+__device__ __forceinline__ void bcast_rec(const IpRec<SH, FAM, KEEP>& m, IpRec<SH, FAM, KEEP>& r) {
   constexpr int NPE = SH::NPE;
+  constexpr bool PF = (FAM != FAM_LE);
+  static_assert(FAM != FAM_PF_MIEHE, "patch kernel carries isotropic-form tangents only");
   r.w = gbcast<NPE, J>(m.w);
 #pragma unroll
   for (int a = 0; a < NPE; a++)
@@ -523,7 +672,7 @@ __device__ __forceinline__ void bcast_rec(const IpRec<SH, PF, KEEP>& m, IpRec<SH
 // then every lane accumulates the rows of its node from the NPE broadcast records (phase 2).
 // Every lane of the group must be active (DPP / bpermute read the other lanes' registers).
 template <class SH, int FAM, bool WANT_K, bool KEEP>
-__device__ __forceinline__ void shared_phase2(const Params& P, int la, const IpRec<SH, FAM != FAM_LE, KEEP>& mine,
+__device__ __forceinline__ void shared_phase2(const Params& P, int la, const IpRec<SH, FAM, KEEP>& mine,
                                               RowBlock<SH, WANT_K, FAM != FAM_LE, KEEP>& R) {
   constexpr int NPE = SH::NPE, NIP = SH::NIP;
   constexpr bool PF = (FAM != FAM_LE);
@@ -531,8 +680,8 @@ __device__ __forceinline__ void shared_phase2(const Params& P, int la, const IpR
   R.zero();
   auto body = [&](auto jc) {
     constexpr int J = decltype(jc)::value;
-    IpRec<SH, PF, KEEP> r;
-    bcast_rec<SH, PF, KEEP, J>(mine, r);
+    IpRec<SH, FAM, KEEP> r;
+    bcast_rec<SH, FAM, KEEP, J>(mine, r);
     double Nip[NPE];
 #pragma unroll
     for (int b = 0; b < NPE; b++) Nip[b] = P.tab[J * NPE + b];
@@ -684,7 +833,7 @@ __global__ __launch_bounds__(SH::PBLOCK) void assemble_patch(const Params P) {
     const bool more = kb + GPB < nelem;
     RowBlock<SH, WANT_K, PF, KEEP> R;
     if constexpr (SH::SHARE) {
-      IpRec<SH, PF, KEEP> mine;
+      IpRec<SH, FAM, KEEP> mine;
       ip_point<SH, FAM, WANT_K, KEEP>(P, cur.e, la, E, H0, owned, mine, err_acc);
       const LaneIdx<NPE> me = cur;
       if (more) {                                            // gathers of the next pass fly during phase 2
@@ -884,6 +1033,8 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_generic(const Params P) {
 template <class SH, int FAM, bool WANT_K, bool KEEP>
 static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
   if (path == PATH_PATCH) {
+    if constexpr (FAM == FAM_PF_MIEHE) return -1000;
+    else {
     auto kern = assemble_patch<SH, FAM, WANT_K, KEEP>;
     const size_t shmem = patch_shmem_bytes(WANT_K ? P.plds : 0, (FAM != FAM_LE) ? SH::RANK + 1 : SH::RANK);
     static size_t configured = 0;                  // per instantiation
@@ -893,6 +1044,7 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
       configured = shmem;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SH::PBLOCK), shmem, st, P);
+    }
   } else if (path == PATH_ROWS) {
     hipLaunchKernelGGL((assemble_rows<SH, FAM, WANT_K, KEEP, false>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
   } else if (path == PATH_ROWS_ORDERED) {
@@ -913,6 +1065,11 @@ static int launch_shape(const Params& P, int fam, bool want_K, bool keep, int pa
     if (!want_K) return launch_one<SH, FAM_PF_ISO, false, false>(P, path, grid, st);
     return keep ? launch_one<SH, FAM_PF_ISO, true, true>(P, path, grid, st)
                 : launch_one<SH, FAM_PF_ISO, true, false>(P, path, grid, st);
+  }
+  if (fam == FAM_PF_MIEHE) {
+    if (!want_K) return launch_one<SH, FAM_PF_MIEHE, false, false>(P, path, grid, st);
+    return keep ? launch_one<SH, FAM_PF_MIEHE, true, true>(P, path, grid, st)
+                : launch_one<SH, FAM_PF_MIEHE, true, false>(P, path, grid, st);
   }
   return -1000;   // family not built for this shape
 }

@@ -89,7 +89,7 @@ def test_linear_elasticity(shape, state2d):
 
 
 @pytest.mark.parametrize("shape", [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2])
-@pytest.mark.parametrize("material", [capi.AMOR_PHASE, capi.BOURDIN_PHASE])
+@pytest.mark.parametrize("material", [capi.AMOR_PHASE, capi.BOURDIN_PHASE, capi.MIEHE_PHASE])
 @pytest.mark.parametrize("keep", [0, 1])
 def test_phase_fracture(shape, material, keep):
     run_both(shape, capi.PHASE_FRACTURE, material, keep=keep)
@@ -99,6 +99,55 @@ def test_phase_fracture(shape, material, keep):
 @pytest.mark.parametrize("model", [capi.PHASE_FRACTURE_EXT, capi.PHASE_FRACTURE_EXTIT])
 def test_phase_fracture_ext(shape, model):
     run_both(shape, model, capi.AMOR_PHASE)
+
+
+@pytest.mark.parametrize("shape", [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2])
+def test_miehe_variants(shape):
+    """MiehePhase (spectral split) through the Ext / ExtIt models, the ordered row kernel, the generic kernel,
+    the WRITTEN pattern on shuffled nodes and the force-only call."""
+    run_both(shape, capi.PHASE_FRACTURE_EXT, capi.MIEHE_PHASE)
+    run_both(shape, capi.PHASE_FRACTURE_EXTIT, capi.MIEHE_PHASE, flags=capi.OVERWRITE | capi.DETERMINISTIC)
+    run_both(shape, capi.PHASE_FRACTURE, capi.MIEHE_PHASE, keep=1, flags=capi.OVERWRITE | capi.FORCE_GENERIC)
+    run_both(shape, capi.PHASE_FRACTURE, capi.MIEHE_PHASE, kind=capi.PATTERN_WRITTEN, flags=capi.ACCUMULATE, shuffle=True)
+    run_both(shape, capi.PHASE_FRACTURE, capi.MIEHE_PHASE, want_K=False)
+
+
+@pytest.mark.parametrize("shape", [capi.QUAD4_G2, capi.HEX8_G2])
+@pytest.mark.parametrize("field", ["zero", "dilation", "compression", "uniaxial", "shear"])
+def test_miehe_degenerate_strains(shape, field):
+    """Repeated / zero principal strains (theta_ab branch of MiehePhaseMaterial.cpp:394-401) on an undistorted grid.
+    The reference's projector is discontinuous where a principal strain crosses zero (diag[i] = eigVal > 0,
+    :372-375), so fields whose principal strains are zero only up to rounding are not comparable between two
+    implementations; the 3D fields below keep every principal strain either exactly repeated or away from zero."""
+    import torch
+    coords, conn = MESH[shape]()
+    rank = coords.shape[1]; nd = rank + 1
+    st = np.zeros(coords.shape[0] * nd)
+    x = coords
+    if field == "dilation":
+        for i in range(rank): st[i::nd] = 1e-3 * x[:, i]
+    elif field == "compression":
+        for i in range(rank): st[i::nd] = -1e-3 * x[:, i]
+    elif field == "uniaxial":
+        st[0::nd] = 2e-3 * x[:, 0]
+        for i in range(1, rank): st[i::nd] = (-0.6e-3 if rank == 3 else 0.0) * x[:, i]
+    elif field == "shear":
+        st[0::nd] = 1e-3 * x[:, 1] + 0.2e-3 * x[:, 0]; st[1::nd] = 1e-3 * x[:, 0]     # tr != 0: heavisideP(tr) is a step too
+        if rank == 3: st[2::nd] = 0.3e-3 * x[:, 2]
+    st[rank::nd] = 0.3 * np.exp(-np.abs(x[:, 1] - 0.5) / 0.3)
+    kw = dict(state=capi.PLANE_STRAIN, young=210.0, poisson=0.3, frac_type=capi.AT2, gc=2.7e-3, l0=0.2, sigma_t=0.0,
+              beta=6500.0, keep_off_diags=1)
+    cfg = po.make_config(shape, capi.PHASE_FRACTURE, capi.MIEHE_PHASE, **kw)
+    asm = capi.Assembler(shape, capi.PHASE_FRACTURE, capi.MIEHE_PHASE, coords, conn, **kw)
+    rp, ci = asm.pattern()
+    dev = torch.device("cuda", 0)
+    K = torch.zeros(asm.nnz, dtype=torch.float64, device=dev); f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+    asm.assemble(torch.from_numpy(st).to(dev), K, f, flags=capi.OVERWRITE)
+    torch.cuda.synchronize()
+    ref = po.assemble(cfg, coords, conn, rp, ci, st)
+    assert rel_rowmax_err(rp, K.cpu().numpy(), ref["K"]) < TOL
+    assert np.abs(f.cpu().numpy() - ref["f"]).max() < TOL * max(np.abs(ref["f"]).max(), 1e-300)
+    assert vec_err(asm.get_history(1), ref["hist_new"]) < TOL if ref["hist_new"].max() > 0 else True
 
 
 @pytest.mark.parametrize("frac", [capi.AT1, capi.CZM_LINEAR, capi.CZM_EXPONENTIAL, capi.CZM_CORNELISSEN,
