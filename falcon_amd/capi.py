@@ -51,7 +51,7 @@ class AssembleArgs(C.Structure):
 EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_nip_total", "fa_ndof_per_node",
            "fa_strain_rows", "fa_uses_row_kernel", "fa_psi0", "fa_patch_stats", "fa_pattern_host", "fa_pattern_device",
            "fa_assemble", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
-           "fa_history_device", "fa_get_strain_cache"]
+           "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables"]
 
 _lib = None
 
@@ -81,6 +81,9 @@ def lib():
         L.fa_set_history.argtypes = [vp, C.c_int32, vp]
         L.fa_history_device.argtypes = [vp, C.c_int32]; L.fa_history_device.restype = vp
         L.fa_get_strain_cache.argtypes = [vp, vp]
+        ip = C.POINTER(C.c_int32)
+        L.fa_shape_info.argtypes = [C.c_int32, ip, ip, ip]
+        L.fa_shape_tables.argtypes = [C.c_int32, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -92,6 +95,15 @@ def _check(rc):
 
 def _np_ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def shape_tables(shape):
+    """(rank, npe, nip, N[nip,npe], dN[nip,npe,rank], w[nip]) of a shape id as the kernels use them (host only)."""
+    r, n, q = C.c_int32(), C.c_int32(), C.c_int32()
+    _check(lib().fa_shape_info(shape, C.byref(r), C.byref(n), C.byref(q)))
+    N = np.empty((q.value, n.value)); dN = np.empty((q.value, n.value, r.value)); w = np.empty(q.value)
+    _check(lib().fa_shape_tables(shape, _np_ptr(N), _np_ptr(dN), _np_ptr(w)))
+    return r.value, n.value, q.value, N, dN, w
 
 
 class Assembler:

@@ -59,6 +59,9 @@ void gauss_line(int n, double* x, double* w) {
   else { x[0] = -std::sqrt(3.0 / 5.0); x[1] = 0; x[2] = -x[0]; w[0] = w[2] = 5.0 / 9.0; w[1] = 8.0 / 9.0; }
 }
 
+// shapes served by the cooperative element kernel instead of the lane-per-(node, element) kernels
+bool coop_shape(int id) { return id != FA_TRI3_G1 && id != FA_QUAD4_G2 && id != FA_HEX8_G2; }
+
 bool make_shape(int id, ShapeTab& s) {
   auto alloc = [&](int rank, int npe, int nip) {
     s.rank = rank; s.npe = npe; s.nip = nip;
@@ -107,6 +110,100 @@ bool make_shape(int id, ShapeTab& s) {
       }
       return true;
     }
+    case FA_TRI3_G3: case FA_TRI6_G3: {
+      // 3-point rule at the "edge-interior" points, weight 1/6 each; Triangle6 in perimeter order
+      // corner-mid-corner-mid-corner-mid (Jive's order)
+      const int npe = (id == FA_TRI3_G3) ? 3 : 6;
+      alloc(2, npe, 3);
+      const double px[3] = { 1.0 / 6.0, 2.0 / 3.0, 1.0 / 6.0 }, py[3] = { 1.0 / 6.0, 1.0 / 6.0, 2.0 / 3.0 };
+      for (int ip = 0; ip < 3; ip++) {
+        const double L[3] = { 1.0 - px[ip] - py[ip], px[ip], py[ip] };
+        const double dL[3][2] = { { -1, -1 }, { 1, 0 }, { 0, 1 } };
+        double* N = &s.N[ip * npe]; double* d = &s.dN[ip * npe * 2];
+        if (npe == 3) {
+          for (int a = 0; a < 3; a++) { N[a] = L[a]; d[a * 2] = dL[a][0]; d[a * 2 + 1] = dL[a][1]; }
+        } else {
+          for (int c = 0; c < 3; c++) {
+            const int n = (c + 1) % 3;                 // corner c -> node 2c; edge (c, c+1) -> node 2c+1
+            N[2 * c] = L[c] * (2 * L[c] - 1);
+            N[2 * c + 1] = 4 * L[c] * L[n];
+            for (int k = 0; k < 2; k++) {
+              d[(2 * c) * 2 + k] = (4 * L[c] - 1) * dL[c][k];
+              d[(2 * c + 1) * 2 + k] = 4 * (L[n] * dL[c][k] + L[c] * dL[n][k]);
+            }
+          }
+        }
+        s.w[ip] = 1.0 / 6.0;
+      }
+      return true;
+    }
+    case FA_QUAD8_G3: case FA_QUAD8_G2: {
+      // serendipity Quad8 in perimeter order corner-mid-corner-mid...
+      const int n = (id == FA_QUAD8_G3) ? 3 : 2;
+      alloc(2, 8, n * n);
+      gauss_line(n, gx, gw);
+      const int cx[8] = { -1, 0, 1, 1, 1, 0, -1, -1 }, cy[8] = { -1, -1, -1, 0, 1, 1, 1, 0 };
+      for (int iy = 0; iy < n; iy++) for (int ix = 0; ix < n; ix++) {
+        const int ip = iy * n + ix;
+        const double x = gx[ix], y = gx[iy];
+        for (int a = 0; a < 8; a++) {
+          const double xa = cx[a], ya = cy[a];
+          double N, dx, dy;
+          if (cx[a] != 0 && cy[a] != 0) {
+            N = 0.25 * (1 + xa * x) * (1 + ya * y) * (xa * x + ya * y - 1);
+            dx = 0.25 * xa * (1 + ya * y) * (2 * xa * x + ya * y);
+            dy = 0.25 * ya * (1 + xa * x) * (xa * x + 2 * ya * y);
+          } else if (cx[a] == 0) {
+            N = 0.5 * (1 - x * x) * (1 + ya * y); dx = -x * (1 + ya * y); dy = 0.5 * ya * (1 - x * x);
+          } else {
+            N = 0.5 * (1 + xa * x) * (1 - y * y); dx = 0.5 * xa * (1 - y * y); dy = -y * (1 + xa * x);
+          }
+          s.N[ip * 8 + a] = N; s.dN[(ip * 8 + a) * 2] = dx; s.dN[(ip * 8 + a) * 2 + 1] = dy;
+        }
+        s.w[ip] = gw[ix] * gw[iy];
+      }
+      return true;
+    }
+    case FA_HEX20_G3: case FA_HEX20_G2: {
+      // serendipity Hex20: bottom-face perimeter (8), vertical mid-edges (4), top-face perimeter (8)
+      // (Jive's Hex20 order is not evidenced by any shipped mesh; generator and table agree)
+      const int n = (id == FA_HEX20_G3) ? 3 : 2;
+      alloc(3, 20, n * n * n);
+      gauss_line(n, gx, gw);
+      int c[20][3];
+      {
+        const int px[8] = { -1, 0, 1, 1, 1, 0, -1, -1 }, py[8] = { -1, -1, -1, 0, 1, 1, 1, 0 };
+        for (int a = 0; a < 8; a++) { c[a][0] = px[a]; c[a][1] = py[a]; c[a][2] = -1; c[12 + a][0] = px[a]; c[12 + a][1] = py[a]; c[12 + a][2] = 1; }
+        for (int a = 0; a < 4; a++) { c[8 + a][0] = px[2 * a]; c[8 + a][1] = py[2 * a]; c[8 + a][2] = 0; }
+      }
+      for (int iz = 0; iz < n; iz++) for (int iy = 0; iy < n; iy++) for (int ix = 0; ix < n; ix++) {
+        const int ip = (iz * n + iy) * n + ix;
+        const double g[3] = { gx[ix], gx[iy], gx[iz] };
+        for (int a = 0; a < 20; a++) {
+          int mid = -1;                                 // direction along which the node sits at 0
+          for (int k = 0; k < 3; k++) if (c[a][k] == 0) mid = k;
+          double f[3];
+          for (int k = 0; k < 3; k++) f[k] = 1 + c[a][k] * g[k];
+          double N, d[3];
+          if (mid < 0) {
+            const double sum = c[a][0] * g[0] + c[a][1] * g[1] + c[a][2] * g[2] - 2;
+            N = 0.125 * f[0] * f[1] * f[2] * sum;
+            for (int k = 0; k < 3; k++) d[k] = 0.125 * c[a][k] * f[(k + 1) % 3] * f[(k + 2) % 3] * (sum + f[k]);
+          } else {
+            const int p = (mid + 1) % 3, q = (mid + 2) % 3;
+            const double q2 = 1 - g[mid] * g[mid];
+            N = 0.25 * q2 * f[p] * f[q];
+            d[mid] = -0.5 * g[mid] * f[p] * f[q];
+            d[p] = 0.25 * c[a][p] * q2 * f[q];
+            d[q] = 0.25 * c[a][q] * q2 * f[p];
+          }
+          s.N[ip * 20 + a] = N;
+          for (int k = 0; k < 3; k++) s.dN[(ip * 20 + a) * 3 + k] = d[k];
+        }
+        s.w[ip] = gw[ix] * gw[iy] * gw[iz];
+      }
+      return true;
+    }
   }
   return false;
 }
@@ -116,6 +213,12 @@ fa::launch_fn launcher_for(int shape) {
     case FA_TRI3_G1:  return fa::launch_tri3_g1;
     case FA_QUAD4_G2: return fa::launch_quad4_g2;
     case FA_HEX8_G2:  return fa::launch_hex8_g2;
+    case FA_TRI3_G3:  return fa::launch_tri3_g3;
+    case FA_TRI6_G3:  return fa::launch_tri6_g3;
+    case FA_QUAD8_G3: return fa::launch_quad8_g3;
+    case FA_QUAD8_G2: return fa::launch_quad8_g2;
+    case FA_HEX20_G3: return fa::launch_hex20_g3;
+    case FA_HEX20_G2: return fa::launch_hex20_g2;
   }
   return nullptr;
 }
@@ -148,7 +251,8 @@ struct fa_ctx {
   fa_problem prob{};
   int rank = 0, npe = 0, nip = 0, str = 0, ndofpn = 0, fam = 0, srows = 0;
   int64_t nnode = 0, nel = 0, ndof = 0, nnz = 0;
-  bool rows_path = false, own_pattern = false;
+  bool rows_path = false, own_pattern = false, coop = false;
+  int ngrid_coop = 0;
   int nwg = 0, max_valence = 0, ngrid_generic = 0, block = 0, npatch = 0, plds = 0;
   bool patch_path = false;
   double lane_redundancy = 1.0;
@@ -184,7 +288,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   c->prob = *p;
   ShapeTab sh;
   if (!make_shape(p->shape, sh))
-    return fail(FA_ERR_UNSUPPORTED, "shape id %d has no gfx950 kernel yet", p->shape);
+    return fail(FA_ERR_ARG, "unknown shape id %d", p->shape);
   c->launch = launcher_for(p->shape);
   c->rank = sh.rank; c->npe = sh.npe; c->nip = sh.nip; c->str = (sh.rank == 2) ? 4 : 6;
   if (p->model < FA_LINEAR_ELASTICITY || p->model > FA_PHASE_FRACTURE_EXTIT) return fail(FA_ERR_ARG, "invalid model %d", p->model);
@@ -373,6 +477,10 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   std::vector<int32_t> wg_start;
   const int kBlock = fa::block_for(rank), kLds = fa::lds_for(rank);
   c->block = kBlock;
+  P.canon = rows_ok ? 1 : 0;                        // canonical blocked layout: entry index from the pos table
+  c->coop = coop_shape(p->shape);
+  c->ngrid_coop = (int)((nel + fa::coop_epb(rank, npe, sh.nip) - 1) / fa::coop_epb(rank, npe, sh.nip));
+  if (c->coop) rows_ok = false;
   if (rows_ok) {
     wg_start.push_back(0);
     int64_t thr = 0, lds = 0, nn = 0;
@@ -442,7 +550,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[1], nipt, 0.0);
   }
   if (p->model == FA_PHASE_FRACTURE_EXTIT)
-    HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(std::max(c->nwg, c->ngrid_generic), c->npatch)));
+    HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(std::max(std::max(c->nwg, c->ngrid_generic), c->npatch), c->ngrid_coop)));
   HIP_TRY(hipDeviceSynchronize());
 
   P.conn = c->d_conn; P.coords = c->d_coords; P.row_ptr = c->d_row_ptr; P.col_idx = c->d_col_idx;
@@ -460,6 +568,24 @@ extern "C" fa_status fa_create(const fa_problem* p, fa_ctx** out) {
   fa_status st = create_impl(p, c);
   if (st != FA_OK) { std::string keep = g_err; fa_destroy(c); g_err = keep; return st; }
   *out = c;
+  return FA_OK;
+}
+
+extern "C" fa_status fa_shape_info(int32_t shape, int32_t* rank, int32_t* npe, int32_t* nip) {
+  ShapeTab sh;
+  if (!make_shape(shape, sh)) return fail(FA_ERR_ARG, "unknown shape id %d", shape);
+  if (rank) *rank = sh.rank;
+  if (npe) *npe = sh.npe;
+  if (nip) *nip = sh.nip;
+  return FA_OK;
+}
+
+extern "C" fa_status fa_shape_tables(int32_t shape, double* N, double* dN, double* w) {
+  ShapeTab sh;
+  if (!make_shape(shape, sh)) return fail(FA_ERR_ARG, "unknown shape id %d", shape);
+  if (N) std::copy(sh.N.begin(), sh.N.end(), N);
+  if (dN) std::copy(sh.dN.begin(), sh.dN.end(), dN);
+  if (w) std::copy(sh.w.begin(), sh.w.end(), w);
   return FA_OK;
 }
 
@@ -509,7 +635,7 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   P.err_part = want_err ? c->d_err_part : nullptr;
   const bool want_K = a->K_values != nullptr;
   const bool keep = want_K && (P.keep2 || P.keep3);
-  int path = fa::PATH_GENERIC;
+  int path = c->coop ? fa::PATH_COOP : fa::PATH_GENERIC;
   if (c->rows_path && !(a->flags & FA_FORCE_GENERIC))
     path = (a->flags & FA_DETERMINISTIC) ? fa::PATH_ROWS_ORDERED : (c->patch_path ? fa::PATH_PATCH : fa::PATH_ROWS);
   if (c->nel == 0) {
@@ -524,7 +650,8 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   if (path == fa::PATH_PATCH) grid = c->npatch;
   else if (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) grid = c->nwg;
   else {
-    grid = c->ngrid_generic;
+    grid = c->coop ? c->ngrid_coop : c->ngrid_generic;
+    if (a->flags & FA_FORCE_GENERIC) P.canon = 0;      // testing: per-entry column search
     if (P.overwrite) {
       if (want_K) HIP_TRY(hipMemsetAsync(a->K_values, 0, sizeof(double) * c->nnz, st));
       HIP_TRY(hipMemsetAsync(a->f_int, 0, sizeof(double) * c->ndof, st));

@@ -32,7 +32,18 @@ constexpr size_t patch_shmem_bytes(int plds, int ndofpn) {     // K image, f ima
 constexpr int prec_own_words(int npe) { return (npe + 1) / 2; }
 constexpr int prec_pos_words(int npe) { return (npe + 3) / 4; }
 constexpr int prec_stride(int npe) { return 1 + npe + prec_own_words(npe) + npe * prec_pos_words(npe); }
-enum { PATH_PATCH = 0, PATH_ROWS = 1, PATH_GENERIC = 2, PATH_ROWS_ORDERED = 3 };
+enum { PATH_PATCH = 0, PATH_ROWS = 1, PATH_GENERIC = 2, PATH_ROWS_ORDERED = 3, PATH_COOP = 4 };
+
+// cooperative element kernel (higher-order shapes): elements per workgroup so that the LDS slots of the largest
+// family (Miehe with off-diagonal blocks) stay below 64 KB
+constexpr int coop_slot_doubles(int rank, int npe, int nip) {
+  const int S = (rank == 2) ? 3 : 6;
+  return (npe + 1) / 2 + npe * (2 * rank + 3) + nip * (1 + npe * rank + rank + (3 + S * S + 2 * S + 4)) + 4;
+}
+constexpr int coop_epb(int rank, int npe, int nip) {
+  const int n = 8000 / coop_slot_doubles(rank, npe, nip);
+  return n < 1 ? 1 : (n > 32 ? 32 : n);
+}
 
 // kernel family: which compute core is instantiated
 enum { FAM_LE = 0, FAM_PF_ISO = 1, FAM_PF_MIEHE = 2 };
@@ -47,6 +58,7 @@ struct Params {
   const int32_t* n2e_ptr;    // nnode+1   node -> incident (element, local node) pairs, element-ascending
   const int32_t* n2e_ent;    // nel*npe   e*npe + la
   const uint8_t* pos;        // nel*npe*npe: position of node conn[e][lb] in the sorted neighbour list of conn[e][la]
+                             // (nullptr when the caller's pattern is not the canonical blocked layout)
   const int32_t* wg_start;   // nwg+1     first node of every workgroup (row kernel)
   // patch kernel: node patches with their halo of elements
   const int32_t* pn_ptr;     // npatch+1  owned nodes of patch p: pnode[pn_ptr[p] .. pn_ptr[p+1]), ascending ids
@@ -69,7 +81,7 @@ struct Params {
   double*        f;
   // ---- sizes / switches ----
   int64_t nnode, nel;
-  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds;
+  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon;
   int32_t cnt[4];            // entries per neighbour node in a row of dof type i
   int32_t off[4][4];         // offset of column type j inside that group, -1 if not in the pattern
   // ---- constants ----
@@ -84,5 +96,11 @@ typedef int (*launch_fn)(const Params& P, int fam, bool want_K, bool keep, int p
 int launch_tri3_g1 (const Params&, int, bool, bool, int, int, void*);
 int launch_quad4_g2(const Params&, int, bool, bool, int, int, void*);
 int launch_hex8_g2 (const Params&, int, bool, bool, int, int, void*);
+int launch_tri3_g3 (const Params&, int, bool, bool, int, int, void*);
+int launch_tri6_g3 (const Params&, int, bool, bool, int, int, void*);
+int launch_quad8_g3(const Params&, int, bool, bool, int, int, void*);
+int launch_quad8_g2(const Params&, int, bool, bool, int, int, void*);
+int launch_hex20_g3(const Params&, int, bool, bool, int, int, void*);
+int launch_hex20_g2(const Params&, int, bool, bool, int, int, void*);
 
 }  // namespace fa

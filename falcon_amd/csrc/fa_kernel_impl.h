@@ -80,19 +80,24 @@ struct RowBlock {
   }
 };
 
-// Everything the row accumulation needs from one Gauss point.
+// Constitutive result of one Gauss point (what Material::update and the degradation terms leave behind).
 template <class SH, int FAM, bool KEEP>
-struct IpRec {
+struct IpMat {
   static constexpr bool PF = (FAM != FAM_LE), GEN = (FAM == FAM_PF_MIEHE);
-  double w;                          // w_ref * det J
-  double g[SH::NPE][SH::RANK];       // dN_a/dx_i
   double d0, d1, d3;                 // tangent D in isotropic form
   double D[GEN ? SH::S : 1][GEN ? SH::S : 1];   // general symmetric tangent (Miehe)
   double sig[SH::S];                 // stress
   double sp[KEEP ? SH::S : 1];       // sigma+ = dPsi/deps (off-diagonal blocks only)
   double c1, cf;                     // N N^T coefficient of K4; N coefficient of f2
   double dg, dgl;                    // g'(phi), loading * g'(phi)
-  double gphi[PF ? SH::RANK : 1];    // grad phi
+};
+
+// Everything the row accumulation needs from one Gauss point.
+template <class SH, int FAM, bool KEEP>
+struct IpRec : IpMat<SH, FAM, KEEP> {
+  double w;                          // w_ref * det J
+  double g[SH::NPE][SH::RANK];       // dN_a/dx_i
+  double gphi[(FAM != FAM_LE) ? SH::RANK : 1];    // grad phi
 };
 
 // gathered nodal data of one element
@@ -330,6 +335,65 @@ __device__ __forceinline__ void Bt_vec(const double (&ga)[RANK], const double (&
   }
 }
 
+// Constitutive part of one Gauss point: degradation, material update, history, phase-field coefficients
+// (PhaseFractureModel.cpp:656-703,714,728; Ext variants PhaseFractureExtModel.cpp:656-758).
+// pf / pf0 / pfX: phase field, old phase field and state00 (Ext) or stateExt_ (ExtIt) interpolated to the point.
+template <class SH, int FAM, bool KEEP>
+__device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, const double (&eps)[SH::S], double pf,
+                                            double pf0, double pfX, double H0, bool write, IpMat<SH, FAM, KEEP>& r,
+                                            double& err_acc) {
+  constexpr int RANK = SH::RANK, S = SH::S, STR = SH::STR;
+  constexpr bool PF = (FAM != FAM_LE);
+  const int srows = PF ? STR + 1 : STR;
+  double sp[S], Psi = 0.0;
+  r.c1 = 0.0; r.cf = 0.0; r.dg = 0.0; r.dgl = 0.0;
+  if constexpr (!PF) {
+    iso_update<RANK, S>(P, eps, 1.0, r.d0, r.d1, r.d3, r.sig, sp, Psi);
+  } else {
+    double dgphi, ddgphi, loading = 1.0;
+    double gmat;
+    if (P.model == 1) {
+      degrade(P, pf, gmat, dgphi, ddgphi);
+    } else {
+      // extrapolated phase field (PhaseFractureExtModel.cpp:656-691, PhaseFractureExtItModel.cpp:693)
+      double pfEx;
+      if (P.model == 2) {
+        if (P.dt0 < 1.e-15) pfEx = pf0;
+        else                pfEx = -pfX * P.dt / P.dt0 + pf0 * (P.dt + P.dt0) / P.dt0;
+      } else {
+        pfEx = pfX;
+        if (write) { const double d = pf - pfEx; err_acc += d * d; }
+      }
+      if (pfEx < 0.0) pfEx = 0.0; else if (pfEx > 1.0) pfEx = 1.0;
+      double t1, t2, t3;
+      degrade(P, pfEx, gmat, t1, t2);
+      degrade(P, pf, t3, dgphi, ddgphi);
+    }
+    if (P.strain != nullptr && write) P.strain[ipoint * srows + STR] = gmat;
+    if constexpr (FAM == FAM_PF_MIEHE) { r.d0 = r.d1 = r.d3 = 0.0; miehe_update<RANK, S>(P, eps, gmat, r.D, r.sig, sp, Psi); }
+    else iso_update<RANK, S>(P, eps, gmat, r.d0, r.d1, r.d3, r.sig, sp, Psi);
+    if (P.model == 1) {                                 // PhaseFractureModel.cpp:696-703
+      if (Psi < H0) loading = 0.0;
+      Psi = (Psi > H0) ? Psi : H0;
+      if (write) P.hist_new[ipoint] = Psi;
+    } else {
+      Psi = (Psi > P.psi0) ? Psi : P.psi0;              // PhaseFractureExtModel.cpp:726
+    }
+    const double dw = P.eta + 2.0 * (1.0 - P.eta) * pf, ddw = 2.0 * (1.0 - P.eta);
+    r.c1 = P.gcl * ddw + ddgphi * Psi;                  // K4 (:714)
+    r.cf = P.gcl * dw + dgphi * Psi;                    // f2 (:728)
+    if ((P.model >= 2) && (pf0 - pf > 1.e-15)) {        // penalty, PhaseFractureExtModel.cpp:752-758
+      r.c1 += P.gcl * P.beta;
+      r.cf -= P.gcl * P.beta * (pf0 - pf);
+    }
+    r.dg = dgphi; r.dgl = loading * dgphi;
+  }
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int c = 0; c < S; c++) r.sp[c] = sp[c];
+  }
+}
+
 // One Gauss point of element e: IShape::getShapeGradients, strain = B u, degradation, material update,
 // history (PhaseFractureModel.cpp:629-703; Ext variants PhaseFractureExtModel.cpp:656-758).
 // `ip` may differ from lane to lane.  `write` = this lane is the one that stores the per-point outputs
@@ -421,12 +485,8 @@ __device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, con
     }
   }
 
-  double sp[S], Psi = 0.0;
-  r.c1 = 0.0; r.cf = 0.0; r.dg = 0.0; r.dgl = 0.0;
-  if constexpr (!PF) {
-    iso_update<RANK, S>(P, eps, 1.0, r.d0, r.d1, r.d3, r.sig, sp, Psi);
-  } else {
-    double pf = 0.0, pf0 = 0.0, dgphi, ddgphi, loading = 1.0;
+  double pf = 0.0, pf0 = 0.0, pfX = 0.0;
+  if constexpr (PF) {
 #pragma unroll
     for (int i = 0; i < RANK; i++) r.gphi[i] = 0.0;
 #pragma unroll
@@ -435,50 +495,12 @@ __device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, con
 #pragma unroll
       for (int i = 0; i < RANK; i++) r.gphi[i] += r.g[a][i] * E.phi[a];
     }
-    double gmat;
-    if (P.model == 1) {
-      degrade(P, pf, gmat, dgphi, ddgphi);
-    } else {
-      // extrapolated phase field (PhaseFractureExtModel.cpp:656-691, PhaseFractureExtItModel.cpp:693)
-      double pfX = 0.0;
+    if (P.model >= 2) {
 #pragma unroll
       for (int a = 0; a < NPE; a++) { pf0 += tabN[ip * NPE + a] * E.phi0[a]; pfX += tabN[ip * NPE + a] * E.phiX[a]; }
-      double pfEx;
-      if (P.model == 2) {
-        if (P.dt0 < 1.e-15) pfEx = pf0;
-        else                pfEx = -pfX * P.dt / P.dt0 + pf0 * (P.dt + P.dt0) / P.dt0;
-      } else {
-        pfEx = pfX;
-        if (write) { const double d = pf - pfEx; err_acc += d * d; }
-      }
-      if (pfEx < 0.0) pfEx = 0.0; else if (pfEx > 1.0) pfEx = 1.0;
-      double t1, t2, t3;
-      degrade(P, pfEx, gmat, t1, t2);
-      degrade(P, pf, t3, dgphi, ddgphi);
     }
-    if (P.strain != nullptr && write) P.strain[ipoint * srows + STR] = gmat;
-    if constexpr (FAM == FAM_PF_MIEHE) { r.d0 = r.d1 = r.d3 = 0.0; miehe_update<RANK, S>(P, eps, gmat, r.D, r.sig, sp, Psi); }
-    else iso_update<RANK, S>(P, eps, gmat, r.d0, r.d1, r.d3, r.sig, sp, Psi);
-    if (P.model == 1) {                                 // PhaseFractureModel.cpp:696-703
-      if (Psi < H0) loading = 0.0;
-      Psi = (Psi > H0) ? Psi : H0;
-      if (write) P.hist_new[ipoint] = Psi;
-    } else {
-      Psi = (Psi > P.psi0) ? Psi : P.psi0;              // PhaseFractureExtModel.cpp:726
-    }
-    const double dw = P.eta + 2.0 * (1.0 - P.eta) * pf, ddw = 2.0 * (1.0 - P.eta);
-    r.c1 = P.gcl * ddw + ddgphi * Psi;                  // K4 (:714)
-    r.cf = P.gcl * dw + dgphi * Psi;                    // f2 (:728)
-    if ((P.model >= 2) && (pf0 - pf > 1.e-15)) {        // penalty, PhaseFractureExtModel.cpp:752-758
-      r.c1 += P.gcl * P.beta;
-      r.cf -= P.gcl * P.beta * (pf0 - pf);
-    }
-    r.dg = dgphi; r.dgl = loading * dgphi;
   }
-  if constexpr (KEEP) {
-#pragma unroll
-    for (int c = 0; c < S; c++) r.sp[c] = sp[c];
-  }
+  ip_material<SH, FAM, KEEP>(P, ipoint, eps, pf, pf0, pfX, H0, write, r, err_acc);
 }
 
 // Rows of local node la from one Gauss-point record.  Nip[b] = N_b(ip).

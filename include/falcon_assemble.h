@@ -108,13 +108,20 @@ int64_t   fa_nnz(const fa_ctx* ctx);
 int64_t   fa_nip_total(const fa_ctx* ctx);
 int32_t   fa_ndof_per_node(const fa_ctx* ctx);
 int32_t   fa_strain_rows(const fa_ctx* ctx);
-/* 1 if the coalesced LDS-staged kernels (patch / row) are used, 0 if the generic atomic-scatter kernel is */
+/* 1 if the coalesced LDS-staged kernels (patch / row) are used, 0 if an atomic-scatter kernel is (generic
+ * kernel; cooperative element kernel of the higher-order shapes) */
 int32_t   fa_uses_row_kernel(const fa_ctx* ctx);
 /* set-up statistics of the patch kernel: number of node patches and Gauss-point redundancy
  * (element evaluations / elements; halo elements are evaluated by every patch they touch).  No reference counterpart. */
 int32_t   fa_patch_stats(const fa_ctx* ctx, double* redundancy);
 /* Psi0_ (PhaseFractureModel.cpp:296-355) */
 double    fa_psi0(const fa_ctx* ctx);
+
+/* The element tables the kernels integrate with (IShapeFactory::newInstance + shape_->getShapeFunctions(),
+ * reference-space gradients and weights behind shape_->getShapeGradients, PhaseFractureModel.cpp:124-128,602).
+ * Host only, no GPU needed.  N[nip*npe], dN[nip*npe*rank], w[nip]; any output pointer may be NULL. */
+fa_status fa_shape_info(int32_t shape, int32_t* rank, int32_t* npe, int32_t* nip);
+fa_status fa_shape_tables(int32_t shape, double* N, double* dN, double* w);
 
 /* CSR pattern hand-off (what the solver wrappers pull: cuDSSSolver.cpp:639-663).  Host copies
  * (either pointer may be NULL) and device-resident pointers. */

@@ -49,3 +49,15 @@ def test_argument_errors_before_any_gpu_call():
         capi.Assembler(capi.QUAD4_G2, capi.LINEAR_ELASTICITY, capi.HOOKE, coords, bad)
     with pytest.raises(capi.FaError, match="rank"):
         capi.Assembler(capi.HEX8_G2, capi.LINEAR_ELASTICITY, capi.HOOKE, coords, conn)
+
+
+@pytest.mark.parametrize("shape", range(9))
+def test_shape_tables_match_the_oracle(shape):
+    """The product's element tables (host code of the library) against the checker's, and partition of unity."""
+    from oracle import pyoracle as po
+    rank, npe, nip, N, dN, w = capi.shape_tables(shape)
+    No, dNo, wo = po.shape_tables(shape)
+    assert N.shape == np.asarray(No).shape and dN.shape == np.asarray(dNo).shape
+    assert np.abs(N - No).max() < 1e-15 and np.abs(dN - dNo).max() < 1e-14 and np.abs(w - wo).max() < 1e-16
+    assert np.abs(N.sum(1) - 1).max() < 1e-14 and np.abs(dN.sum(1)).max() < 1e-14
+    assert abs(w.sum() - {2: 4.0, 3: 8.0}[rank] * (0.125 if npe in (3, 6) else 1.0)) < 1e-14

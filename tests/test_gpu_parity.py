@@ -13,7 +13,11 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-12
 
 MESH = {capi.TRI3_G1: lambda: meshgen.grid_tri3(9, 7), capi.QUAD4_G2: lambda: meshgen.grid_quad4(11, 9),
-        capi.HEX8_G2: lambda: meshgen.grid_hex8(5, 4, 3)}
+        capi.HEX8_G2: lambda: meshgen.grid_hex8(5, 4, 3),
+        capi.TRI3_G3: lambda: meshgen.grid_tri3(8, 9), capi.TRI6_G3: lambda: meshgen.grid_tri6(6, 5),
+        capi.QUAD8_G3: lambda: meshgen.grid_quad8(7, 5), capi.QUAD8_G2: lambda: meshgen.grid_quad8(6, 7),
+        capi.HEX20_G3: lambda: meshgen.grid_hex20(3, 4, 3), capi.HEX20_G2: lambda: meshgen.grid_hex20(4, 3, 3)}
+HIGH_ORDER = [capi.TRI3_G3, capi.TRI6_G3, capi.QUAD8_G3, capi.QUAD8_G2, capi.HEX20_G3, capi.HEX20_G2]
 
 
 def vec_err(got, ref):
@@ -23,7 +27,8 @@ def vec_err(got, ref):
 def make_case(shape, model, material, keep=0, frac=capi.AT2, state2d=capi.PLANE_STRAIN, shuffle=False, seed=1,
               sigma_t=0.0, young=210.0, gc=2.7e-3, l0=0.2):
     coords, conn = MESH[shape]()
-    coords = meshgen.distort(coords, conn, 0.15, seed)
+    linear = shape in (capi.TRI3_G1, capi.TRI3_G3, capi.QUAD4_G2, capi.HEX8_G2)
+    coords = meshgen.distort(coords, conn, 0.15 if linear else 0.06, seed)    # quadratic elements: mid nodes at h/2
     if shuffle:
         coords, conn, _ = meshgen.shuffle_nodes(coords, conn, seed)
     rank = coords.shape[1]
@@ -297,3 +302,27 @@ def test_empty_and_single_element():
     assert asm0.nnz == 0
     K, f, _ = asm0.assemble_host(u, np.zeros(0), np.ones(6), flags=capi.OVERWRITE)
     assert np.all(f == 0)
+
+
+# ---- higher-order shapes (cooperative element kernel) ----
+@pytest.mark.parametrize("shape", HIGH_ORDER)
+def test_high_order_linear_elasticity(shape):
+    """BASELINE config 5 family: LinearElasticity + Hooke on Hex20 (Gauss3^3 / Gauss2^3), and the 2D shapes."""
+    asm = run_both(shape, capi.LINEAR_ELASTICITY, capi.HOOKE)
+    assert not asm.uses_row_kernel
+    run_both(shape, capi.LINEAR_ELASTICITY, capi.HOOKE, state2d=capi.PLANE_STRESS, flags=capi.ACCUMULATE, shuffle=True)
+
+
+@pytest.mark.parametrize("shape", HIGH_ORDER)
+@pytest.mark.parametrize("material", [capi.AMOR_PHASE, capi.BOURDIN_PHASE, capi.MIEHE_PHASE])
+def test_high_order_phase_fracture(shape, material):
+    run_both(shape, capi.PHASE_FRACTURE, material, keep=0)
+    run_both(shape, capi.PHASE_FRACTURE, material, keep=1, kind=capi.PATTERN_WRITTEN, shuffle=True)
+    run_both(shape, capi.PHASE_FRACTURE, material, want_K=False)
+
+
+@pytest.mark.parametrize("shape", HIGH_ORDER)
+def test_high_order_ext_models_and_column_search(shape):
+    run_both(shape, capi.PHASE_FRACTURE_EXT, capi.AMOR_PHASE)
+    run_both(shape, capi.PHASE_FRACTURE_EXTIT, capi.MIEHE_PHASE, flags=capi.ACCUMULATE)
+    run_both(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, keep=1, flags=capi.OVERWRITE | capi.FORCE_GENERIC)
