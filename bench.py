@@ -7,7 +7,8 @@ over the whole synthetic mesh, inputs resident in HBM.  N=1 workload = BASELINE.
 scaling, one 4000x(4000) strip per GPU stacked in y, interface f_int entries summed with the
 neighbouring ranks over RCCL (falcon_amd/distributed.py); value = all ranks' elements / max time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4] [--n SIZE]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5|cfg5g2] [--n SIZE]
+                    [--material amor|miehe|bourdin] [--keep-off-diags] [--mode ...] [--pattern ...] [--force-only]
 """
 import argparse
 import json
@@ -29,7 +30,9 @@ def algorithmic_bytes(nnz_written, ndof, nnode, rank, npe, nel, nip, phase_field
     return b
 
 
-def workload(name, n, capi):
+def workload(name, n, capi, material="amor", keep=False):
+    mat = {"amor": capi.AMOR_PHASE, "miehe": capi.MIEHE_PHASE, "bourdin": capi.BOURDIN_PHASE}[material]
+    mname = {"amor": "AmorPhase", "miehe": "MiehePhase", "bourdin": "BourdinPhase"}[material]
     if name == "cfg2":
         n = n or 1000
         return dict(desc=f"cfg2: {n}x{n} Q4 linear-elastic plate (Hooke, plane strain)", shape=capi.QUAD4_G2,
@@ -37,15 +40,22 @@ def workload(name, n, capi):
                     written_per_pair=4, kw=dict(young=210e3, poisson=0.3))
     if name == "cfg3":
         n = n or 4000
-        return dict(desc=f"cfg3: {n}x{n} Q4 single-edge-notched tension, phase-field fracture (u-phi), AT2, AmorPhase, "
-                         "keepOffDiags=false", shape=capi.QUAD4_G2, model=capi.PHASE_FRACTURE,
-                    material=capi.AMOR_PHASE, dims=(n, n), h=1.0 / n, written_per_pair=5,
-                    kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=False))
+        return dict(desc=f"cfg3: {n}x{n} Q4 single-edge-notched tension, phase-field fracture (u-phi), AT2, {mname}, "
+                         f"keepOffDiags={'true' if keep else 'false'}", shape=capi.QUAD4_G2, model=capi.PHASE_FRACTURE,
+                    material=mat, dims=(n, n), h=1.0 / n, written_per_pair=9 if keep else 5,
+                    kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=keep))
     if name == "cfg4":
         n = n or 200
-        return dict(desc=f"cfg4: {n}^3 hex8 phase-field fracture cube, AT2, AmorPhase", shape=capi.HEX8_G2,
-                    model=capi.PHASE_FRACTURE, material=capi.AMOR_PHASE, dims=(n, n, n), h=1.0 / n,
-                    written_per_pair=10, kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2))
+        return dict(desc=f"cfg4: {n}^3 hex8 phase-field fracture cube, AT2, {mname}", shape=capi.HEX8_G2,
+                    model=capi.PHASE_FRACTURE, material=mat, dims=(n, n, n), h=1.0 / n,
+                    written_per_pair=16 if keep else 10,
+                    kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=keep))
+    if name in ("cfg5", "cfg5g2"):
+        n = n or 64
+        g3 = name == "cfg5"
+        return dict(desc=f"cfg5: {n}^3 hex20 linear-elastic block (Hooke), Gauss{'3' if g3 else '2'}^3",
+                    shape=capi.HEX20_G3 if g3 else capi.HEX20_G2, model=capi.LINEAR_ELASTICITY, material=capi.HOOKE,
+                    dims=(n, n, n), h=1.0 / n, written_per_pair=9, kw=dict(young=210e3, poisson=0.3))
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -59,8 +69,9 @@ def cpu_baseline(wl, capi, meshgen, target_elems):
         sample = f"{m}x{m} Q4 sub-grid of the same mesh (same h, material, state field), one K+f_int pass"
     else:
         m = max(4, int(round(target_elems ** (1.0 / 3.0))))
-        coords, conn = meshgen.grid_hex8(m, m, m, m * wl["h"], m * wl["h"], m * wl["h"])
-        sample = f"{m}^3 hex8 sub-grid of the same mesh, one K+f_int pass"
+        gen = meshgen.grid_hex20 if wl["shape"] in (7, 8) else meshgen.grid_hex8
+        coords, conn = gen(m, m, m, m * wl["h"], m * wl["h"], m * wl["h"])
+        sample = f"{m}^3 sub-grid of the same mesh, one K+f_int pass"
     kw = dict(wl["kw"])
     cfg = po.make_config(wl["shape"], wl["model"], wl["material"], young=kw["young"], poisson=kw["poisson"],
                          gc=kw.get("gc", 2.7), l0=kw.get("l0", 0.015), frac_type=kw.get("frac_type", 1),
@@ -84,6 +95,8 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="elements per side (default: the BASELINE size)")
     ap.add_argument("--mode", default="overwrite", choices=["overwrite", "accumulate"])
     ap.add_argument("--pattern", default="full", choices=["full", "written"])
+    ap.add_argument("--material", default="amor", choices=["amor", "miehe", "bourdin"])
+    ap.add_argument("--keep-off-diags", action="store_true")
     ap.add_argument("--force-only", action="store_true", help="GET_INT_VECTOR pass instead of GET_MATRIX0")
     ap.add_argument("--cpu-elems", type=int, default=2250000, help="elements in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -106,7 +119,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    wl = workload(args.workload, args.n, capi)
+    wl = workload(args.workload, args.n, capi, args.material, args.keep_off_diags)
     rk = len(wl["dims"])
     t_setup = time.perf_counter()
     part = None
@@ -119,13 +132,14 @@ def main():
             coords, conn = meshgen.grid_quad4(nx, ny, nx * wl["h"], ny * wl["h"])
     else:
         nx, ny, nz = wl["dims"]
-        coords, conn = meshgen.grid_hex8(nx, ny, nz, nx * wl["h"], ny * wl["h"], nz * wl["h"])
+        gen = meshgen.grid_hex20 if wl["shape"] in (capi.HEX20_G3, capi.HEX20_G2) else meshgen.grid_hex8
+        coords, conn = gen(nx, ny, nz, nx * wl["h"], ny * wl["h"], nz * wl["h"])
         if world > 1:
             raise SystemExit("multi-GPU bench is implemented for the 2D strip partition")
     kind = capi.PATTERN_FULL if args.pattern == "full" else capi.PATTERN_WRITTEN
     asm = capi.Assembler(wl["shape"], wl["model"], wl["material"], coords, conn, pattern_kind=kind,
                          device=local_rank, **wl["kw"])
-    assert asm.uses_row_kernel
+    assert asm.uses_row_kernel or wl["shape"] in (capi.HEX20_G3, capi.HEX20_G2)
     state = torch.from_numpy(meshgen.smooth_state(coords, asm.ndofpn, seed=12345 + rank)).to(dev)
     del coords
     want_K = not args.force_only
@@ -179,6 +193,8 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             key = f"{args.workload}:{asm.nel}:{args.mode}:{args.pattern}:{'f' if args.force_only else 'K'}"
+            if args.material != "amor" or args.keep_off_diags:
+                key += f":{args.material}:{int(args.keep_off_diags)}"
             traffic = json.load(open(tf)).get(key)
         out = {
             "metric": "assembled elements/sec (K + f_int)" if want_K else "assembled elements/sec (f_int only)",

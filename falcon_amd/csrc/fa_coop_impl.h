@@ -12,6 +12,14 @@
 #pragma once
 #include "fa_kernel_impl.h"
 
+// the node / Gauss-point loops stay rolled: unrolled 20 x 27 they need > 256 VGPRs and spill
+#ifndef FA_COOP_UNROLL_A
+#define FA_COOP_UNROLL_A 1
+#endif
+#ifndef FA_COOP_UNROLL_IP
+#define FA_COOP_UNROLL_IP 1
+#endif
+
 namespace fa {
 
 template <class SH, int FAM, bool KEEP>
@@ -72,6 +80,7 @@ __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
     for (int i = 0; i < RANK; i++)
 #pragma unroll
       for (int k = 0; k < RANK; k++) J[i][k] = 0.0;
+#pragma unroll FA_COOP_UNROLL_A
     for (int a = 0; a < NPE; a++) {
 #pragma unroll
       for (int k = 0; k < RANK; k++) {
@@ -108,6 +117,7 @@ __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
     for (int c = 0; c < S; c++) eps[c] = 0.0;
 #pragma unroll
     for (int i = 0; i < RANK; i++) gphi[i] = 0.0;
+#pragma unroll FA_COOP_UNROLL_A
     for (int a = 0; a < NPE; a++) {
       double ga[RANK], ua[RANK];
 #pragma unroll
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
     double fu[RANK], fp = 0.0;
 #pragma unroll
     for (int i = 0; i < RANK; i++) fu[i] = 0.0;
+#pragma unroll FA_COOP_UNROLL_IP
     for (int ip = 0; ip < NIP; ip++) {
       const double w = L.w[ip];
       double wga[RANK], tt[RANK], sig[S];
@@ -198,6 +209,7 @@ __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
 #pragma unroll
         for (int j = 0; j < RANK; j++) Kuu[i][j] = 0.0;
       }
+#pragma unroll FA_COOP_UNROLL_IP
       for (int ip = 0; ip < NIP; ip++) {
         const IpMat<SH, FAM, KEEP>& m = L.m[ip];
         const double w = L.w[ip];

@@ -915,6 +915,10 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
   __shared__ double sErr[kBlock / 64];
 
   const int tid = threadIdx.x;
+#if defined(FA_STAGGER)
+  // experiment: offset the phases of the workgroups that share a CU
+  if (FA_STAGGER_COND) { for (int k = 0; k < FA_STAGGER; k++) __builtin_amdgcn_s_sleep(127); }
+#endif
   const int n0 = P.wg_start[blockIdx.x], n1 = P.wg_start[blockIdx.x + 1];
   const int64_t base = P.row_ptr[(int64_t)n0 * NDOF];
   const int len = WANT_K ? (int)(P.row_ptr[(int64_t)n1 * NDOF] - base) : 0;
