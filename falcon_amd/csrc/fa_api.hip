@@ -261,7 +261,7 @@ struct fa_ctx {
   // device
   int32_t* d_conn = nullptr; double* d_coords = nullptr; int64_t* d_row_ptr = nullptr; int32_t* d_col_idx = nullptr;
   int64_t* d_node_dofs = nullptr; int32_t* d_n2e_ptr = nullptr; int32_t* d_n2e_ent = nullptr; uint8_t* d_pos = nullptr;
-  int32_t* d_wg_start = nullptr; double* d_tab = nullptr;
+  int32_t* d_wg_start = nullptr; double* d_tab = nullptr; int32_t* d_lrec = nullptr; int32_t* d_wginfo = nullptr;
   int32_t *d_pn_ptr = nullptr, *d_pe_ptr = nullptr, *d_pr_ptr = nullptr, *d_pnode = nullptr, *d_poff = nullptr,
           *d_prec = nullptr, *d_prun = nullptr;
   double* d_hist[2] = { nullptr, nullptr };   // [0] preHist_, [1] newHist_
@@ -277,7 +277,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->prob.device);
   void* ptrs[] = { c->d_conn, c->d_coords, c->d_row_ptr, c->d_col_idx, c->d_node_dofs, c->d_n2e_ptr, c->d_n2e_ent,
-                   c->d_pos, c->d_wg_start, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part,
+                   c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part,
                    c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err,
                    c->d_pn_ptr, c->d_pe_ptr, c->d_pr_ptr, c->d_pnode, c->d_poff, c->d_prec, c->d_prun };
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -496,6 +496,38 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     wg_start.push_back((int32_t)nnode);
   }
   c->rows_path = rows_ok;
+  // ---- lane records / workgroup descriptors of the row kernel ----
+  std::vector<int32_t> lrec, wginfo;
+  if (rows_ok) {
+    const int LS = fa::lrec_stride(npe);
+    const int64_t nwg = (int64_t)wg_start.size() - 1;
+    lrec.assign(((size_t)nel * npe + 1) * LS, 0);          // + one padding record (idle lanes of an empty workgroup)
+    wginfo.assign((size_t)nwg * fa::kWgInfo, 0);
+    parallel_for(nwg, [&](int64_t wb, int64_t we) {
+      for (int64_t w = wb; w < we; w++) {
+        const int64_t n0 = wg_start[w], n1 = wg_start[w + 1];
+        const int64_t base = h_rp[n0 * nd];
+        int32_t* wi = wginfo.data() + w * fa::kWgInfo;
+        wi[0] = (int32_t)n0; wi[1] = (int32_t)n1; wi[2] = n2e_ptr[n0]; wi[3] = n2e_ptr[n1] - n2e_ptr[n0];
+        wi[4] = (int32_t)(uint32_t)(base & 0xFFFFFFFFLL); wi[5] = (int32_t)(base >> 32);
+        wi[6] = (int32_t)(h_rp[n1 * nd] - base);
+        for (int64_t n = n0; n < n1; n++) {
+          const uint32_t w0 = (uint32_t)(h_rp[n * nd] - base) | ((uint32_t)(n - n0) << 16) |
+                              ((uint32_t)(nb_ptr[n + 1] - nb_ptr[n]) << 24);
+          for (int32_t t = n2e_ptr[n]; t < n2e_ptr[n + 1]; t++) {
+            int32_t* r = lrec.data() + (size_t)t * LS;
+            const int32_t ent = n2e_ent[t];
+            const int64_t el = ent / npe; const int la = ent - (int32_t)el * npe;
+            r[0] = ent;
+            for (int b = 0; b < npe; b++) r[1 + b] = p->conn[el * npe + b];
+            r[1 + npe] = (int32_t)w0;
+            for (int b = 0; b < npe; b++)
+              r[2 + npe + (b >> 2)] |= (int32_t)((uint32_t)pos[((size_t)el * npe + la) * npe + b] << (8 * (b & 3)));
+          }
+        }
+      }
+    });
+  }
   // ---- node patches (patch kernel) ----
   fa::PatchSet ps;
   if (rows_ok && nel > 0 && c->fam != fa::FAM_PF_MIEHE && getenv("FA_USE_PATCH")) {               // experimental, opt-in
@@ -525,7 +557,11 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   if ((st = upload(&c->d_n2e_ptr, n2e_ptr.data(), n2e_ptr.size()))) return st;
   if ((st = upload(&c->d_n2e_ent, n2e_ent.data(), n2e_ent.size()))) return st;
   if ((st = upload(&c->d_pos, pos.data(), pos.size()))) return st;
-  if (rows_ok) { if ((st = upload(&c->d_wg_start, wg_start.data(), wg_start.size()))) return st; }
+  if (rows_ok) {
+    if ((st = upload(&c->d_wg_start, wg_start.data(), wg_start.size()))) return st;
+    if ((st = upload(&c->d_lrec, lrec.data(), lrec.size()))) return st;
+    if ((st = upload(&c->d_wginfo, wginfo.data(), wginfo.size()))) return st;
+  }
   if (c->patch_path) {
     if ((st = upload(&c->d_pn_ptr, ps.pn_ptr.data(), ps.pn_ptr.size()))) return st;
     if ((st = upload(&c->d_pe_ptr, ps.pe_ptr.data(), ps.pe_ptr.size()))) return st;
@@ -555,7 +591,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
 
   P.conn = c->d_conn; P.coords = c->d_coords; P.row_ptr = c->d_row_ptr; P.col_idx = c->d_col_idx;
   P.node_dofs = c->d_node_dofs; P.n2e_ptr = c->d_n2e_ptr; P.n2e_ent = c->d_n2e_ent; P.pos = c->d_pos;
-  P.wg_start = c->d_wg_start; P.tab = c->d_tab; P.max_valence = c->max_valence;
+  P.wg_start = c->d_wg_start; P.lrec = c->d_lrec; P.wginfo = c->d_wginfo; P.tab = c->d_tab; P.max_valence = c->max_valence;
   P.pn_ptr = c->d_pn_ptr; P.pe_ptr = c->d_pe_ptr; P.pr_ptr = c->d_pr_ptr; P.pnode = c->d_pnode; P.poff = c->d_poff;
   P.prec = c->d_prec; P.prun = c->d_prun; P.plds = c->plds;
   return FA_OK;

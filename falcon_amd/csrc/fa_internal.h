@@ -32,6 +32,12 @@ constexpr size_t patch_shmem_bytes(int plds, int ndofpn) {     // K image, f ima
 constexpr int prec_own_words(int npe) { return (npe + 1) / 2; }
 constexpr int prec_pos_words(int npe) { return (npe + 3) / 4; }
 constexpr int prec_stride(int npe) { return 1 + npe + prec_own_words(npe) + npe * prec_pos_words(npe); }
+// row kernel: one record per lane (= per (node, incident element) pair, in n2e order), so that a lane needs a single
+// coalesced read before its nodal gathers: [0] e*npe + la, [1..npe] element nodes, [npe+1] LDS offset of the node's
+// first row | (node - n0) << 16 | neighbour count << 24, then npe bytes of column positions; padded to 16 bytes.
+constexpr int lrec_stride(int npe) { return ((2 + npe + (npe + 3) / 4) + 3) / 4 * 4; }
+// per workgroup: n0, n1, first lane t0, lane count, CSR base (lo, hi), image length, 0
+constexpr int kWgInfo = 8;
 enum { PATH_PATCH = 0, PATH_ROWS = 1, PATH_GENERIC = 2, PATH_ROWS_ORDERED = 3, PATH_COOP = 4 };
 
 // cooperative element kernel (higher-order shapes): elements per workgroup so that the LDS slots of the largest
@@ -60,6 +66,8 @@ struct Params {
   const uint8_t* pos;        // nel*npe*npe: position of node conn[e][lb] in the sorted neighbour list of conn[e][la]
                              // (nullptr when the caller's pattern is not the canonical blocked layout)
   const int32_t* wg_start;   // nwg+1     first node of every workgroup (row kernel)
+  const int32_t* lrec;       // nel*npe * lrec_stride(npe)  lane records of the row kernel
+  const int32_t* wginfo;     // nwg * kWgInfo
   // patch kernel: node patches with their halo of elements
   const int32_t* pn_ptr;     // npatch+1  owned nodes of patch p: pnode[pn_ptr[p] .. pn_ptr[p+1]), ascending ids
   const int32_t* pe_ptr;     // npatch+1  elements touching patch p: pelem[pe_ptr[p] .. pe_ptr[p+1])

@@ -919,17 +919,25 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
   // experiment: offset the phases of the workgroups that share a CU
   if (FA_STAGGER_COND) { for (int k = 0; k < FA_STAGGER; k++) __builtin_amdgcn_s_sleep(127); }
 #endif
-  const int n0 = P.wg_start[blockIdx.x], n1 = P.wg_start[blockIdx.x + 1];
-  const int64_t base = P.row_ptr[(int64_t)n0 * NDOF];
-  const int len = WANT_K ? (int)(P.row_ptr[(int64_t)n1 * NDOF] - base) : 0;
+  // workgroup descriptor: one scalar load instead of the wg_start -> n2e_ptr / row_ptr chain
+  const int32_t* __restrict__ wi = P.wginfo + (int64_t)blockIdx.x * kWgInfo;
+  const int n0 = wi[0], n1 = wi[1], t0 = wi[2], nlane = wi[3];
+  const int64_t base = ((int64_t)(uint32_t)wi[4]) | ((int64_t)wi[5] << 32);
+  const int len = WANT_K ? wi[6] : 0;
   const int nf = (n1 - n0) * NDOF;
+  const bool active = tid < nlane;
+  // lane record: element, its nodes, row offset / neighbour count of this lane's node, column positions
+  constexpr int LS = lrec_stride(NPE);
+  int32_t rec[LS];
+  {
+    const int4* __restrict__ rp4 = (const int4*)(P.lrec + ((int64_t)t0 + (active ? tid : 0)) * LS);
+#pragma unroll
+    for (int q = 0; q < LS / 4; q++) { const int4 v = rp4[q]; rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w; }
+  }
   if constexpr (WANT_K)
     for (int i = tid; i < len; i += kBlock) sK[i] = 0.0;
   for (int i = tid; i < nf; i += kBlock) sF[i] = 0.0;
 
-  const int t0 = P.n2e_ptr[n0], t1 = P.n2e_ptr[n1];
-  const int t = t0 + tid;
-  const bool active = t < t1;
   RowBlock<SH, WANT_K, PF, KEEP> R;
   int32_t cn[NPE];
   int la = 0, slot = -1, a = n0, rs0 = 0, nnb = 0;
@@ -937,19 +945,14 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
   uint8_t ps[NPE];
   double err_acc = 0.0;
   if (active) {
-    const int ent = P.n2e_ent[t];
-    e = ent / NPE; la = ent - (int)e * NPE;
+    e = rec[0] / NPE; la = rec[0] - (int)e * NPE;
 #pragma unroll
-    for (int b = 0; b < NPE; b++) cn[b] = P.conn[e * NPE + b];
+    for (int b = 0; b < NPE; b++) cn[b] = rec[1 + b];
+    const uint32_t w0 = (uint32_t)rec[1 + NPE];
+    rs0 = (int)(w0 & 0xFFFFu); a = n0 + (int)((w0 >> 16) & 0xFFu); nnb = (int)(w0 >> 24);
 #pragma unroll
-    for (int b = 0; b < NPE; b++) if (b == la) a = cn[b];
-    slot = t - P.n2e_ptr[a];
-    if constexpr (WANT_K) {                        // row start / column positions: issued before the compute
-      const int64_t r0 = P.row_ptr[(int64_t)a * NDOF], r1 = P.row_ptr[(int64_t)a * NDOF + 1];
-      rs0 = (int)(r0 - base); nnb = (int)(r1 - r0) / P.cnt[0];
-#pragma unroll
-      for (int b = 0; b < NPE; b++) ps[b] = P.pos[(e * NPE + la) * NPE + b];
-    }
+    for (int b = 0; b < NPE; b++) ps[b] = (uint8_t)((uint32_t)rec[2 + NPE + (b >> 2)] >> (8 * (b & 3)));
+    if constexpr (ORDERED) slot = t0 + tid - P.n2e_ptr[a];
     compute_rowblock<SH, FAM, WANT_K, KEEP>(P, e, la, cn, true, R, err_acc);
   }
   __syncthreads();
