@@ -684,7 +684,7 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   }
   int grid;
   if (path == fa::PATH_PATCH) grid = c->npatch;
-  else if (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) grid = c->nwg;
+  else if (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) { P.ntile = c->nwg; grid = (c->nwg + 7) / 8 * 8; }
   else {
     grid = c->coop ? c->ngrid_coop : c->ngrid_generic;
     if (a->flags & FA_FORCE_GENERIC) P.canon = 0;      // testing: per-entry column search
@@ -697,7 +697,8 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   if (rc == -1000) return fail(FA_ERR_UNSUPPORTED, "kernel family not built for this shape");
   if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   if (want_err) {
-    hipLaunchKernelGGL(reduce_err_kernel, dim3(1), dim3(256), 0, st, c->d_err_part, grid, a->err_ext);
+    const int nparts = (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) ? c->nwg : grid;
+    hipLaunchKernelGGL(reduce_err_kernel, dim3(1), dim3(256), 0, st, c->d_err_part, nparts, a->err_ext);
     HIP_TRY(hipGetLastError());
   }
   return FA_OK;

@@ -920,7 +920,12 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
   if (FA_STAGGER_COND) { for (int k = 0; k < FA_STAGGER; k++) __builtin_amdgcn_s_sleep(127); }
 #endif
   // workgroup descriptor: one scalar load instead of the wg_start -> n2e_ptr / row_ptr chain
-  const int32_t* __restrict__ wi = P.wginfo + (int64_t)blockIdx.x * kWgInfo;
+  // blockIdx % 8 is the XCD: give every XCD one contiguous band of tiles, so that the tile rows that gather the
+  // same nodes meet in one L2
+  const int per = (int)gridDim.x >> 3;                 // the grid is a multiple of 8
+  const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (tile >= P.ntile) return;
+  const int32_t* __restrict__ wi = P.wginfo + (int64_t)tile * kWgInfo;
   const int n0 = wi[0], n1 = wi[1], t0 = wi[2], nlane = wi[3];
   const int64_t base = ((int64_t)(uint32_t)wi[4]) | ((int64_t)wi[5] << 32);
   const int len = WANT_K ? wi[6] : 0;
@@ -981,7 +986,7 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
     if (P.overwrite) for (int i = tid; i < nf; i += kBlock) fg[i] = sF[i];
     else             for (int i = tid; i < nf; i += kBlock) fg[i] += sF[i];
   }
-  if (PF && P.err_part != nullptr) reduce_err<kBlock>(err_acc, sErr, &P.err_part[blockIdx.x]);
+  if (PF && P.err_part != nullptr) reduce_err<kBlock>(err_acc, sErr, &P.err_part[tile]);
 }
 
 // ------------------------------------------------------------------------------------------------
