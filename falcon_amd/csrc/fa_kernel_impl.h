@@ -40,6 +40,26 @@ struct Shape {
   static constexpr bool SHARE = (NIP_ == NPE_) && (64 % NPE_ == 0);   // group shares the Gauss points
 };
 
+// What a kernel instantiation knows at compile time about the model.  SpecRuntime reads everything from Params
+// (uniform branches); SpecFixed folds model / degradation exponent / material into the code and promises the
+// canonical dof numbering (the row kernels' precondition), which removes every uniform branch from the Gauss-point loop.
+struct SpecRuntime {
+  static __device__ __forceinline__ int model(const Params& P) { return P.model; }
+  static __device__ __forceinline__ int ptype(const Params& P) { return P.ptype; }
+  static __device__ __forceinline__ int material(const Params& P) { return P.material; }
+  static __device__ __forceinline__ bool custom_dofs(const Params& P) { return P.node_dofs != nullptr; }
+};
+struct SpecCanon : SpecRuntime {                       // runtime model, canonical dofs
+  static __device__ __forceinline__ bool custom_dofs(const Params&) { return false; }
+};
+template <int MODEL, int PTYPE, int MAT>
+struct SpecFixed {
+  static __device__ __forceinline__ constexpr int model(const Params&) { return MODEL; }
+  static __device__ __forceinline__ constexpr int ptype(const Params&) { return PTYPE; }
+  static __device__ __forceinline__ constexpr int material(const Params&) { return MAT; }
+  static __device__ __forceinline__ constexpr bool custom_dofs(const Params&) { return false; }
+};
+
 template <int I, int N>
 struct SFor {
   template <class F> static __device__ __forceinline__ void run(F& f) { f(std::integral_constant<int, I>{}); SFor<I + 1, N>::run(f); }
@@ -107,7 +127,7 @@ struct ElemData {
   double phi[PF ? SH::NPE : 1], phi0[PF ? SH::NPE : 1], phiX[PF ? SH::NPE : 1];
 };
 
-template <class SH, bool PF>
+template <class SH, bool PF, class SP = SpecRuntime>
 __device__ __forceinline__ void gather_elem(const Params& P, const int32_t (&cn)[SH::NPE], ElemData<SH, PF>& E) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NDOF = PF ? RANK + 1 : RANK;
 #pragma unroll
@@ -116,12 +136,12 @@ __device__ __forceinline__ void gather_elem(const Params& P, const int32_t (&cn)
     // XDofSpace::getDofIndices: node-major, type-minor unless the caller supplied its own dof map
     int64_t dofs[NDOF];
 #pragma unroll
-    for (int i = 0; i < NDOF; i++) dofs[i] = P.node_dofs ? P.node_dofs[n * NDOF + i] : n * NDOF + i;
+    for (int i = 0; i < NDOF; i++) dofs[i] = SP::custom_dofs(P) ? P.node_dofs[n * NDOF + i] : n * NDOF + i;
 #pragma unroll
     for (int i = 0; i < RANK; i++) { E.x[a][i] = P.coords[n * RANK + i]; E.u[a][i] = P.state[dofs[i]]; }
     if constexpr (PF) {
       E.phi[a] = P.state[dofs[RANK]];
-      if (P.model >= 2) { E.phi0[a] = P.state0[dofs[RANK]]; E.phiX[a] = P.stateX[dofs[RANK]]; }
+      if (SP::model(P) >= 2) { E.phi0[a] = P.state0[dofs[RANK]]; E.phiX[a] = P.stateX[dofs[RANK]]; }
       else { E.phi0[a] = 0.0; E.phiX[a] = 0.0; }
     }
   }
@@ -129,11 +149,12 @@ __device__ __forceinline__ void gather_elem(const Params& P, const int32_t (&cn)
 
 // rational degradation function and its derivatives (PhaseFractureModel.cpp:660-676).
 // ptype: 0 -> p = 2, 1 -> p = 2.5, 2 -> p = 4; pow(x,0) == 1 also at x == 0.
+template <class SP = SpecRuntime>
 __device__ __forceinline__ void degrade(const Params& P, double pf, double& g, double& dg, double& ddg) {
   const double x = 1.0 - pf;
   double gn, dgn, ddgn;
-  if (P.ptype == 0)      { gn = x * x;               dgn = -2.0 * x;            ddgn = 2.0; }
-  else if (P.ptype == 1) { const double sq = sqrt(x);
+  if (SP::ptype(P) == 0)      { gn = x * x;               dgn = -2.0 * x;            ddgn = 2.0; }
+  else if (SP::ptype(P) == 1) { const double sq = sqrt(x);
                            gn = x * x * sq;          dgn = -2.5 * (x * sq);     ddgn = 2.5 * 1.5 * sq; }
   else                   { const double x2 = x * x;
                            gn = x2 * x2;             dgn = -4.0 * (x2 * x);     ddgn = 4.0 * 3.0 * x2; }
@@ -152,13 +173,13 @@ __device__ __forceinline__ void degrade(const Params& P, double pf, double& g, d
 //   material 0: Hooke (HookeMaterial.cpp:152-166), 1: AmorPhase (AmorPhaseMaterial.cpp:200-232),
 //   2: BourdinPhase (BourdinPhaseMaterial.cpp:131-145).
 // e: strain with S components (2D: xx, yy, gamma_xy -- eps_zz is identically 0 because B row 2 is 0).
-template <int RANK, int S>
+template <int RANK, int S, class SP = SpecRuntime>
 __device__ __forceinline__ void iso_update(const Params& P, const double (&e)[S], double g,
                                            double& d0, double& d1, double& d3,
                                            double (&sig)[S], double (&sp)[S], double& Psi) {
   constexpr int NN = RANK;                                  // normal components carried
   const double tr = (RANK == 3) ? (e[0] + e[1] + e[2]) : (e[0] + e[1] + 0.0);
-  if (P.material == 1) {
+  if (SP::material(P) == 1) {
     double dd = 2.0 * P.G * (2.0 / 3.0), od = 2.0 * P.G * (-1.0 / 3.0);
     const double sh = 2.0 * P.G * 0.5;
     if (tr > 0.0) { dd += P.Kb; od += P.Kb; }
@@ -338,7 +359,7 @@ __device__ __forceinline__ void Bt_vec(const double (&ga)[RANK], const double (&
 // Constitutive part of one Gauss point: degradation, material update, history, phase-field coefficients
 // (PhaseFractureModel.cpp:656-703,714,728; Ext variants PhaseFractureExtModel.cpp:656-758).
 // pf / pf0 / pfX: phase field, old phase field and state00 (Ext) or stateExt_ (ExtIt) interpolated to the point.
-template <class SH, int FAM, bool KEEP>
+template <class SH, int FAM, bool KEEP, class SP = SpecRuntime>
 __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, const double (&eps)[SH::S], double pf,
                                             double pf0, double pfX, double H0, bool write, IpMat<SH, FAM, KEEP>& r,
                                             double& err_acc) {
@@ -348,16 +369,16 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
   double sp[S], Psi = 0.0;
   r.c1 = 0.0; r.cf = 0.0; r.dg = 0.0; r.dgl = 0.0;
   if constexpr (!PF) {
-    iso_update<RANK, S>(P, eps, 1.0, r.d0, r.d1, r.d3, r.sig, sp, Psi);
+    iso_update<RANK, S, SP>(P, eps, 1.0, r.d0, r.d1, r.d3, r.sig, sp, Psi);
   } else {
     double dgphi, ddgphi, loading = 1.0;
     double gmat;
-    if (P.model == 1) {
-      degrade(P, pf, gmat, dgphi, ddgphi);
+    if (SP::model(P) == 1) {
+      degrade<SP>(P, pf, gmat, dgphi, ddgphi);
     } else {
       // extrapolated phase field (PhaseFractureExtModel.cpp:656-691, PhaseFractureExtItModel.cpp:693)
       double pfEx;
-      if (P.model == 2) {
+      if (SP::model(P) == 2) {
         if (P.dt0 < 1.e-15) pfEx = pf0;
         else                pfEx = -pfX * P.dt / P.dt0 + pf0 * (P.dt + P.dt0) / P.dt0;
       } else {
@@ -366,13 +387,13 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
       }
       if (pfEx < 0.0) pfEx = 0.0; else if (pfEx > 1.0) pfEx = 1.0;
       double t1, t2, t3;
-      degrade(P, pfEx, gmat, t1, t2);
-      degrade(P, pf, t3, dgphi, ddgphi);
+      degrade<SP>(P, pfEx, gmat, t1, t2);
+      degrade<SP>(P, pf, t3, dgphi, ddgphi);
     }
     if (P.strain != nullptr && write) P.strain[ipoint * srows + STR] = gmat;
     if constexpr (FAM == FAM_PF_MIEHE) { r.d0 = r.d1 = r.d3 = 0.0; miehe_update<RANK, S>(P, eps, gmat, r.D, r.sig, sp, Psi); }
-    else iso_update<RANK, S>(P, eps, gmat, r.d0, r.d1, r.d3, r.sig, sp, Psi);
-    if (P.model == 1) {                                 // PhaseFractureModel.cpp:696-703
+    else iso_update<RANK, S, SP>(P, eps, gmat, r.d0, r.d1, r.d3, r.sig, sp, Psi);
+    if (SP::model(P) == 1) {                                 // PhaseFractureModel.cpp:696-703
       if (Psi < H0) loading = 0.0;
       Psi = (Psi > H0) ? Psi : H0;
       if (write) P.hist_new[ipoint] = Psi;
@@ -382,7 +403,7 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
     const double dw = P.eta + 2.0 * (1.0 - P.eta) * pf, ddw = 2.0 * (1.0 - P.eta);
     r.c1 = P.gcl * ddw + ddgphi * Psi;                  // K4 (:714)
     r.cf = P.gcl * dw + dgphi * Psi;                    // f2 (:728)
-    if ((P.model >= 2) && (pf0 - pf > 1.e-15)) {        // penalty, PhaseFractureExtModel.cpp:752-758
+    if ((SP::model(P) >= 2) && (pf0 - pf > 1.e-15)) {        // penalty, PhaseFractureExtModel.cpp:752-758
       r.c1 += P.gcl * P.beta;
       r.cf -= P.gcl * P.beta * (pf0 - pf);
     }
@@ -398,7 +419,7 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
 // history (PhaseFractureModel.cpp:629-703; Ext variants PhaseFractureExtModel.cpp:656-758).
 // `ip` may differ from lane to lane.  `write` = this lane is the one that stores the per-point outputs
 // (history, strain cache, errExt_).
-template <class SH, int FAM, bool WANT_K, bool KEEP>
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP = SpecRuntime>
 __device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, const ElemData<SH, FAM != FAM_LE>& E,
                                          double H0, bool write, IpRec<SH, FAM, KEEP>& r, double& err_acc) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, S = SH::S, STR = SH::STR;
@@ -495,12 +516,12 @@ __device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, con
 #pragma unroll
       for (int i = 0; i < RANK; i++) r.gphi[i] += r.g[a][i] * E.phi[a];
     }
-    if (P.model >= 2) {
+    if (SP::model(P) >= 2) {
 #pragma unroll
       for (int a = 0; a < NPE; a++) { pf0 += tabN[ip * NPE + a] * E.phi0[a]; pfX += tabN[ip * NPE + a] * E.phiX[a]; }
     }
   }
-  ip_material<SH, FAM, KEEP>(P, ipoint, eps, pf, pf0, pfX, H0, write, r, err_acc);
+  ip_material<SH, FAM, KEEP, SP>(P, ipoint, eps, pf, pf0, pfX, H0, write, r, err_acc);
 }
 
 // Rows of local node la from one Gauss-point record.  Nip[b] = N_b(ip).
@@ -618,7 +639,7 @@ __device__ __forceinline__ void accum_rows(const Params& P, const IpRec<SH, FAM,
 }
 
 // Gauss-point loop of element e done by ONE lane, keeping the rows of local node la.
-template <class SH, int FAM, bool WANT_K, bool KEEP>
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP = SpecRuntime>
 __device__ __forceinline__ void compute_rowblock(const Params& P, int64_t e, int la, const int32_t (&cn)[SH::NPE],
                                                  bool owned, RowBlock<SH, WANT_K, FAM != FAM_LE, KEEP>& R,
                                                  double& err_acc) {
@@ -628,13 +649,13 @@ __device__ __forceinline__ void compute_rowblock(const Params& P, int64_t e, int
 #pragma unroll
   for (int ip = 0; ip < NIP; ip++) H0v[ip] = 0.0;
   if constexpr (PF) {
-    if (P.model == 1) {
+    if (SP::model(P) == 1) {
 #pragma unroll
       for (int ip = 0; ip < NIP; ip++) H0v[ip] = P.hist_pre[e * NIP + ip];
     }
   }
   ElemData<SH, PF> E;
-  gather_elem<SH, PF>(P, cn, E);
+  gather_elem<SH, PF, SP>(P, cn, E);
   R.zero();
 #pragma unroll 1
   for (int ip = 0; ip < NIP; ip++) {
@@ -642,7 +663,7 @@ __device__ __forceinline__ void compute_rowblock(const Params& P, int64_t e, int
     double H0 = 0.0;
 #pragma unroll
     for (int k = 0; k < NIP; k++) if (k == ip) H0 = H0v[k];
-    ip_point<SH, FAM, WANT_K, KEEP>(P, e, ip, E, H0, owned && ((ip % NPE) == la), r, err_acc);
+    ip_point<SH, FAM, WANT_K, KEEP, SP>(P, e, ip, E, H0, owned && ((ip % NPE) == la), r, err_acc);
     double Nip[NPE];
 #pragma unroll
     for (int b = 0; b < NPE; b++) Nip[b] = P.tab[ip * NPE + b];
@@ -905,7 +926,7 @@ __global__ __launch_bounds__(SH::PBLOCK) void assemble_patch(const Params P) {
 // ------------------------------------------------------------------------------------------------
 // Row-gather kernel on contiguous node ranges, deterministic summation order (FA_DETERMINISTIC)
 // ------------------------------------------------------------------------------------------------
-template <class SH, int FAM, bool WANT_K, bool KEEP, bool ORDERED>
+template <class SH, int FAM, bool WANT_K, bool KEEP, bool ORDERED, class SP>
 __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, kBlock = SH::BLOCK, kLdsDoubles = SH::LDS;
   constexpr bool PF = (FAM != FAM_LE);
@@ -958,7 +979,7 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
 #pragma unroll
     for (int b = 0; b < NPE; b++) ps[b] = (uint8_t)((uint32_t)rec[2 + NPE + (b >> 2)] >> (8 * (b & 3)));
     if constexpr (ORDERED) slot = t0 + tid - P.n2e_ptr[a];
-    compute_rowblock<SH, FAM, WANT_K, KEEP>(P, e, la, cn, true, R, err_acc);
+    compute_rowblock<SH, FAM, WANT_K, KEEP, SP>(P, e, la, cn, true, R, err_acc);
   }
   __syncthreads();
 
@@ -1079,10 +1100,22 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SH::PBLOCK), shmem, st, P);
     }
-  } else if (path == PATH_ROWS) {
-    hipLaunchKernelGGL((assemble_rows<SH, FAM, WANT_K, KEEP, false>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
-  } else if (path == PATH_ROWS_ORDERED) {
-    hipLaunchKernelGGL((assemble_rows<SH, FAM, WANT_K, KEEP, true>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
+  } else if (path == PATH_ROWS || path == PATH_ROWS_ORDERED) {
+    // the common configurations get a kernel with model / exponent / material folded in
+    const bool ord = path == PATH_ROWS_ORDERED;
+    auto go = [&](auto spec) {
+      using SP = decltype(spec);
+      if (ord) hipLaunchKernelGGL((assemble_rows<SH, FAM, WANT_K, KEEP, true, SP>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
+      else     hipLaunchKernelGGL((assemble_rows<SH, FAM, WANT_K, KEEP, false, SP>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
+    };
+    if constexpr (FAM == FAM_LE) go(SpecFixed<0, 0, 0>{});
+    else if constexpr (FAM == FAM_PF_ISO) {
+      if (P.model == 1 && P.ptype == 0 && P.material == 1) go(SpecFixed<1, 0, 1>{});
+      else go(SpecCanon{});
+    } else {
+      if (P.model == 1 && P.ptype == 0) go(SpecFixed<1, 0, 3>{});
+      else go(SpecCanon{});
+    }
   } else {
     hipLaunchKernelGGL((assemble_generic<SH, FAM, WANT_K, KEEP>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
   }
