@@ -254,14 +254,15 @@ struct fa_ctx {
   bool rows_path = false, own_pattern = false, coop = false;
   int ngrid_coop = 0;
   int nwg = 0, max_valence = 0, ngrid_generic = 0, block = 0, npatch = 0, plds = 0;
-  bool patch_path = false;
+  bool patch_path = false, pair_path = false;
+  int ntile2 = 0;
   double lane_redundancy = 1.0;
   fa::launch_fn launch = nullptr;
   fa::Params P{};
   // device
   int32_t* d_conn = nullptr; double* d_coords = nullptr; int64_t* d_row_ptr = nullptr; int32_t* d_col_idx = nullptr;
   int64_t* d_node_dofs = nullptr; int32_t* d_n2e_ptr = nullptr; int32_t* d_n2e_ent = nullptr; uint8_t* d_pos = nullptr;
-  int32_t* d_wg_start = nullptr; double* d_tab = nullptr; int32_t* d_lrec = nullptr; int32_t* d_wginfo = nullptr;
+  int32_t* d_wg_start = nullptr; double* d_tab = nullptr; int32_t* d_lrec = nullptr; int32_t* d_wginfo = nullptr; int32_t* d_lrec2 = nullptr; int32_t* d_wginfo2 = nullptr;
   int32_t *d_pn_ptr = nullptr, *d_pe_ptr = nullptr, *d_pr_ptr = nullptr, *d_pnode = nullptr, *d_poff = nullptr,
           *d_prec = nullptr, *d_prun = nullptr;
   double* d_hist[2] = { nullptr, nullptr };   // [0] preHist_, [1] newHist_
@@ -277,7 +278,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->prob.device);
   void* ptrs[] = { c->d_conn, c->d_coords, c->d_row_ptr, c->d_col_idx, c->d_node_dofs, c->d_n2e_ptr, c->d_n2e_ent,
-                   c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part,
+                   c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part,
                    c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err,
                    c->d_pn_ptr, c->d_pe_ptr, c->d_pr_ptr, c->d_pnode, c->d_poff, c->d_prec, c->d_prun };
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -528,6 +529,97 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       }
     });
   }
+  // ---- pair tiling (row kernel with Gauss points shared by lane pairs; Quad4 / Hex8) ----
+  std::vector<int32_t> lrec2, wginfo2;
+  if (rows_ok && nel > 0 && sh.nip % 2 == 0 && !getenv("FA_NO_PAIR")) {
+    const int LS = fa::lrec_stride2(npe), HALF = sh.nip / 2;
+    // greedy tiles: an element with k nodes in the tile takes 2*ceil(k/2) lanes
+    std::vector<int32_t> stamp(nel, -1), cnt_in(nel, 0), tstart;
+    std::vector<int64_t> lane0;                       // first lane of every tile
+    int64_t lanes_total = 0; int tile = 0; int64_t thr = 0, lds = 0, nn = 0;
+    bool ok = true;
+    tstart.push_back(0); lane0.push_back(0);
+    for (int64_t n = 0; n < nnode && ok; n++) {
+      const int64_t l = h_rp[(n + 1) * nd] - h_rp[n * nd];
+      auto delta = [&](int t) {
+        int64_t d = 0;
+        for (int32_t k = n2e_ptr[n]; k < n2e_ptr[n + 1]; k++) {
+          const int32_t el = n2e_ent[k] / npe;
+          const int c0 = (stamp[el] == t) ? cnt_in[el] : 0;
+          if ((c0 & 1) == 0) d += 2;
+        }
+        return d;
+      };
+      int64_t d = delta(tile);
+      if (thr + d > kBlock || lds + l > kLds || nn + 1 > kBlock) {
+        lanes_total += thr; tile++; tstart.push_back((int32_t)n); lane0.push_back(lanes_total);
+        thr = lds = nn = 0;
+        d = delta(tile);
+        if (d > kBlock || l > kLds) { ok = false; break; }
+      }
+      for (int32_t k = n2e_ptr[n]; k < n2e_ptr[n + 1]; k++) {
+        const int32_t el = n2e_ent[k] / npe;
+        if (stamp[el] != tile) { stamp[el] = tile; cnt_in[el] = 0; }
+        cnt_in[el]++;
+      }
+      thr += d; lds += l; nn++;
+    }
+    if (ok) {
+      lanes_total += thr; tstart.push_back((int32_t)nnode); lane0.push_back(lanes_total);
+      const int64_t nt = (int64_t)tstart.size() - 1;
+      lrec2.assign((size_t)(lanes_total + 2) * LS, 0);
+      wginfo2.assign((size_t)nt * fa::kWgInfo, 0);
+      parallel_for(nt, [&](int64_t wb, int64_t we) {
+        struct Ent { int32_t el, la, node; };
+        std::vector<Ent> ents;
+        for (int64_t w = wb; w < we; w++) {
+          const int64_t n0 = tstart[w], n1 = tstart[w + 1];
+          const int64_t base = h_rp[n0 * nd];
+          ents.clear();
+          for (int64_t n = n0; n < n1; n++)
+            for (int32_t t = n2e_ptr[n]; t < n2e_ptr[n + 1]; t++) ents.push_back({ n2e_ent[t] / npe, n2e_ent[t] % npe, (int32_t)n });
+          std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.el < b.el; });
+          int32_t* wi = wginfo2.data() + w * fa::kWgInfo;
+          int64_t lane = lane0[w];
+          wi[0] = (int32_t)n0; wi[1] = (int32_t)n1; wi[2] = (int32_t)(uint32_t)(lane & 0xFFFFFFFFLL); wi[7] = (int32_t)(lane >> 32);
+          wi[3] = (int32_t)(lane0[w + 1] - lane0[w]);
+          wi[4] = (int32_t)(uint32_t)(base & 0xFFFFFFFFLL); wi[5] = (int32_t)(base >> 32);
+          wi[6] = (int32_t)(h_rp[n1 * nd] - base);
+          auto emit = [&](const Ent& en, bool owner, int half, uint32_t wmask) {
+            int32_t* r = lrec2.data() + (size_t)lane * LS;
+            const int64_t n = en.node;
+            r[0] = en.el * npe + en.la;
+            for (int b = 0; b < npe; b++) r[1 + b] = p->conn[(int64_t)en.el * npe + b];
+            r[1 + npe] = (int32_t)((uint32_t)(h_rp[n * nd] - base) | ((uint32_t)(n - n0) << 16) |
+                                   ((uint32_t)(nb_ptr[n + 1] - nb_ptr[n]) << 24));
+            for (int b = 0; b < npe; b++)
+              r[2 + npe + (b >> 2)] |= (int32_t)((uint32_t)pos[((size_t)en.el * npe + en.la) * npe + b] << (8 * (b & 3)));
+            r[LS - 1] = (int32_t)((owner ? 1u : 0u) | ((uint32_t)half << 1) | (wmask << 2));
+            lane++;
+          };
+          for (size_t i = 0; i < ents.size();) {
+            size_t j = i;
+            while (j < ents.size() && ents[j].el == ents[i].el) j++;
+            // Gauss point ip is stored by the pair that holds local node ip % npe (every (element, node) lane exists
+            // exactly once over all tiles), by its lane of half ip / HALF
+            for (size_t q = i; q < j; q += 2) {
+              const bool two = q + 1 < j;
+              const Ent& A = ents[q]; const Ent& B = two ? ents[q + 1] : ents[q];
+              uint32_t wm[2] = { 0, 0 };
+              for (int ip = 0; ip < sh.nip; ip++) {
+                const int lw = ip % npe;
+                if (lw == A.la || (two && lw == B.la)) wm[ip / HALF] |= 1u << (ip % HALF);
+              }
+              emit(A, true, 0, wm[0]);
+              emit(B, two, 1, wm[1]);
+            }
+            i = j;
+          }
+        }
+      });
+      c->pair_path = true; c->ntile2 = (int)nt;
+    }
+  }
   // ---- node patches (patch kernel) ----
   fa::PatchSet ps;
   if (rows_ok && nel > 0 && c->fam != fa::FAM_PF_MIEHE && getenv("FA_USE_PATCH")) {               // experimental, opt-in
@@ -562,6 +654,10 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     if ((st = upload(&c->d_lrec, lrec.data(), lrec.size()))) return st;
     if ((st = upload(&c->d_wginfo, wginfo.data(), wginfo.size()))) return st;
   }
+  if (c->pair_path) {
+    if ((st = upload(&c->d_lrec2, lrec2.data(), lrec2.size()))) return st;
+    if ((st = upload(&c->d_wginfo2, wginfo2.data(), wginfo2.size()))) return st;
+  }
   if (c->patch_path) {
     if ((st = upload(&c->d_pn_ptr, ps.pn_ptr.data(), ps.pn_ptr.size()))) return st;
     if ((st = upload(&c->d_pe_ptr, ps.pe_ptr.data(), ps.pe_ptr.size()))) return st;
@@ -586,12 +682,12 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[1], nipt, 0.0);
   }
   if (p->model == FA_PHASE_FRACTURE_EXTIT)
-    HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(std::max(std::max(c->nwg, c->ngrid_generic), c->npatch), c->ngrid_coop)));
+    HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(std::max(std::max(std::max(c->nwg, c->ntile2), c->ngrid_generic), c->npatch), c->ngrid_coop)));
   HIP_TRY(hipDeviceSynchronize());
 
   P.conn = c->d_conn; P.coords = c->d_coords; P.row_ptr = c->d_row_ptr; P.col_idx = c->d_col_idx;
   P.node_dofs = c->d_node_dofs; P.n2e_ptr = c->d_n2e_ptr; P.n2e_ent = c->d_n2e_ent; P.pos = c->d_pos;
-  P.wg_start = c->d_wg_start; P.lrec = c->d_lrec; P.wginfo = c->d_wginfo; P.tab = c->d_tab; P.max_valence = c->max_valence;
+  P.wg_start = c->d_wg_start; P.lrec = c->d_lrec; P.wginfo = c->d_wginfo; P.lrec2 = c->d_lrec2; P.wginfo2 = c->d_wginfo2; P.ntile2 = c->ntile2; P.tab = c->d_tab; P.max_valence = c->max_valence;
   P.pn_ptr = c->d_pn_ptr; P.pe_ptr = c->d_pe_ptr; P.pr_ptr = c->d_pr_ptr; P.pnode = c->d_pnode; P.poff = c->d_poff;
   P.prec = c->d_prec; P.prun = c->d_prun; P.plds = c->plds;
   return FA_OK;
@@ -673,7 +769,7 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   const bool keep = want_K && (P.keep2 || P.keep3);
   int path = c->coop ? fa::PATH_COOP : fa::PATH_GENERIC;
   if (c->rows_path && !(a->flags & FA_FORCE_GENERIC))
-    path = (a->flags & FA_DETERMINISTIC) ? fa::PATH_ROWS_ORDERED : (c->patch_path ? fa::PATH_PATCH : fa::PATH_ROWS);
+    path = (a->flags & FA_DETERMINISTIC) ? fa::PATH_ROWS_ORDERED : (c->patch_path ? fa::PATH_PATCH : (c->pair_path ? fa::PATH_ROWS_PAIR : fa::PATH_ROWS));
   if (c->nel == 0) {
     if (P.overwrite) {
       if (want_K) HIP_TRY(hipMemsetAsync(a->K_values, 0, sizeof(double) * c->nnz, st));
@@ -685,6 +781,7 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   int grid;
   if (path == fa::PATH_PATCH) grid = c->npatch;
   else if (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) { P.ntile = c->nwg; grid = (c->nwg + 7) / 8 * 8; }
+  else if (path == fa::PATH_ROWS_PAIR) grid = (c->ntile2 + 7) / 8 * 8;
   else {
     grid = c->coop ? c->ngrid_coop : c->ngrid_generic;
     if (a->flags & FA_FORCE_GENERIC) P.canon = 0;      // testing: per-entry column search
@@ -697,7 +794,7 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   if (rc == -1000) return fail(FA_ERR_UNSUPPORTED, "kernel family not built for this shape");
   if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   if (want_err) {
-    const int nparts = (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) ? c->nwg : grid;
+    const int nparts = (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) ? c->nwg : (path == fa::PATH_ROWS_PAIR ? c->ntile2 : grid);
     hipLaunchKernelGGL(reduce_err_kernel, dim3(1), dim3(256), 0, st, c->d_err_part, nparts, a->err_ext);
     HIP_TRY(hipGetLastError());
   }

@@ -36,9 +36,11 @@ constexpr int prec_stride(int npe) { return 1 + npe + prec_own_words(npe) + npe 
 // coalesced read before its nodal gathers: [0] e*npe + la, [1..npe] element nodes, [npe+1] LDS offset of the node's
 // first row | (node - n0) << 16 | neighbour count << 24, then npe bytes of column positions; padded to 16 bytes.
 constexpr int lrec_stride(int npe) { return ((2 + npe + (npe + 3) / 4) + 3) / 4 * 4; }
-// per workgroup: n0, n1, first lane t0, lane count, CSR base (lo, hi), image length, 0
+// pair kernel: the same record plus a flag word in the last slot (bit 0 owner, bit 1 half, bits 2.. store masks)
+constexpr int lrec_stride2(int npe) { return ((3 + npe + (npe + 3) / 4) + 3) / 4 * 4; }
+// per workgroup: n0, n1, first lane t0 (lo), lane count, CSR base (lo, hi), image length, t0 (hi)
 constexpr int kWgInfo = 8;
-enum { PATH_PATCH = 0, PATH_ROWS = 1, PATH_GENERIC = 2, PATH_ROWS_ORDERED = 3, PATH_COOP = 4 };
+enum { PATH_PATCH = 0, PATH_ROWS = 1, PATH_GENERIC = 2, PATH_ROWS_ORDERED = 3, PATH_COOP = 4, PATH_ROWS_PAIR = 5 };
 
 // cooperative element kernel (higher-order shapes): elements per workgroup so that the LDS slots of the largest
 // family (Miehe with off-diagonal blocks) stay below 64 KB
@@ -68,6 +70,8 @@ struct Params {
   const int32_t* wg_start;   // nwg+1     first node of every workgroup (row kernel)
   const int32_t* lrec;       // nel*npe * lrec_stride(npe)  lane records of the row kernel
   const int32_t* wginfo;     // nwg * kWgInfo
+  const int32_t* lrec2;      // pair kernel: lane records / workgroup descriptors of its own tiling
+  const int32_t* wginfo2;
   // patch kernel: node patches with their halo of elements
   const int32_t* pn_ptr;     // npatch+1  owned nodes of patch p: pnode[pn_ptr[p] .. pn_ptr[p+1]), ascending ids
   const int32_t* pe_ptr;     // npatch+1  elements touching patch p: pelem[pe_ptr[p] .. pe_ptr[p+1])
@@ -89,7 +93,7 @@ struct Params {
   double*        f;
   // ---- sizes / switches ----
   int64_t nnode, nel;
-  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile;
+  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2;
   int32_t cnt[4];            // entries per neighbour node in a row of dof type i
   int32_t off[4][4];         // offset of column type j inside that group, -1 if not in the pattern
   // ---- constants ----

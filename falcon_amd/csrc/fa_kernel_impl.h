@@ -1011,6 +1011,151 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row kernel with Gauss points shared by lane pairs (Quad4, Hex8: NIP even)
+// ------------------------------------------------------------------------------------------------
+// Same tiles and LDS row image as assemble_rows, but the lanes come in aligned pairs (2k, 2k+1) that work on the
+// same element: lane "half" h evaluates the Gauss points [h*NIP/2, (h+1)*NIP/2), the two lanes swap every
+// Gauss-point record through a DPP quad permute and each accumulates the rows of its own node from both.  An
+// element with a single node in the tile still gets two lanes; the second one only helps (flag bit 0 clear).
+// Per lane: NIP/2 Gauss points instead of NIP.  Record word LS-1: bit 0 owner, bit 1 half, bits 2.. = "this lane
+// stores the per-point outputs (history, strain cache, errExt_) of its k-th point".
+template <class T>
+__device__ __forceinline__ T pair_swap(T v) {
+  static_assert(sizeof(T) == 8, "doubles");
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <class SH, int FAM, bool KEEP>
+__device__ __forceinline__ void swap_rec(const IpRec<SH, FAM, KEEP>& m, IpRec<SH, FAM, KEEP>& r) {
+  constexpr bool PF = (FAM != FAM_LE), GEN = (FAM == FAM_PF_MIEHE);
+  r.w = pair_swap(m.w);
+#pragma unroll
+  for (int a = 0; a < SH::NPE; a++)
+#pragma unroll
+    for (int i = 0; i < SH::RANK; i++) r.g[a][i] = pair_swap(m.g[a][i]);
+  if constexpr (GEN) {
+#pragma unroll
+    for (int i = 0; i < SH::S; i++)
+#pragma unroll
+      for (int j = i; j < SH::S; j++) { r.D[i][j] = pair_swap(m.D[i][j]); r.D[j][i] = r.D[i][j]; }
+    r.d0 = r.d1 = r.d3 = 0.0;
+  } else {
+    r.d0 = pair_swap(m.d0); r.d1 = pair_swap(m.d1); r.d3 = pair_swap(m.d3);
+  }
+#pragma unroll
+  for (int c = 0; c < SH::S; c++) r.sig[c] = pair_swap(m.sig[c]);
+  r.c1 = r.cf = r.dg = r.dgl = 0.0;
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int c = 0; c < SH::S; c++) r.sp[c] = pair_swap(m.sp[c]);
+    r.dg = pair_swap(m.dg); r.dgl = pair_swap(m.dgl);
+  }
+  if constexpr (PF) {
+    r.c1 = pair_swap(m.c1); r.cf = pair_swap(m.cf);
+#pragma unroll
+    for (int i = 0; i < SH::RANK; i++) r.gphi[i] = pair_swap(m.gphi[i]);
+  }
+}
+
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP>
+__global__ __launch_bounds__(SH::BLOCK) void assemble_rows_pair(const Params P) {
+  constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, HALF = SH::NIP / 2, kBlock = SH::BLOCK, kLdsDoubles = SH::LDS;
+  constexpr bool PF = (FAM != FAM_LE);
+  constexpr int NDOF = PF ? RANK + 1 : RANK;
+  static_assert(NIP % 2 == 0, "pairs split the Gauss points in halves");
+  __shared__ double sK[WANT_K ? kLdsDoubles : 1];
+  __shared__ double sF[kBlock * NDOF];
+  __shared__ double sErr[kBlock / 64];
+
+  const int tid = threadIdx.x;
+  const int per = (int)gridDim.x >> 3;                 // XCD bands as in assemble_rows
+  const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (tile >= P.ntile2) return;
+  const int32_t* __restrict__ wi = P.wginfo2 + (int64_t)tile * kWgInfo;
+  const int n0 = wi[0], n1 = wi[1], nlane = wi[3];
+  const int64_t t0 = ((int64_t)(uint32_t)wi[2]) | ((int64_t)wi[7] << 32);
+  const int64_t base = ((int64_t)(uint32_t)wi[4]) | ((int64_t)wi[5] << 32);
+  const int len = WANT_K ? wi[6] : 0;
+  const int nf = (n1 - n0) * NDOF;
+  const bool active = tid < nlane;                     // nlane is even: pairs are active together
+  constexpr int LS = lrec_stride2(NPE);
+  int32_t rec[LS];
+  {
+    const int4* __restrict__ rp4 = (const int4*)(P.lrec2 + (t0 + (active ? tid : 0)) * LS);
+#pragma unroll
+    for (int q = 0; q < LS / 4; q++) { const int4 v = rp4[q]; rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w; }
+  }
+  if constexpr (WANT_K)
+    for (int i = tid; i < len; i += kBlock) sK[i] = 0.0;
+  for (int i = tid; i < nf; i += kBlock) sF[i] = 0.0;
+
+  RowBlock<SH, WANT_K, PF, KEEP> R;
+  int32_t cn[NPE];
+  int la = 0, aloc = 0, rs0 = 0, nnb = 0;
+  bool owner = false;
+  uint8_t ps[NPE];
+  double err_acc = 0.0;
+  if (active) {
+    const int64_t e = rec[0] / NPE; la = rec[0] - (int)e * NPE;
+#pragma unroll
+    for (int b = 0; b < NPE; b++) cn[b] = rec[1 + b];
+    const uint32_t w0 = (uint32_t)rec[1 + NPE];
+    rs0 = (int)(w0 & 0xFFFFu); aloc = (int)((w0 >> 16) & 0xFFu); nnb = (int)(w0 >> 24);
+#pragma unroll
+    for (int b = 0; b < NPE; b++) ps[b] = (uint8_t)((uint32_t)rec[2 + NPE + (b >> 2)] >> (8 * (b & 3)));
+    const uint32_t fl = (uint32_t)rec[LS - 1];
+    owner = fl & 1u;
+    const int half = (fl >> 1) & 1;
+    double H0v[HALF];
+#pragma unroll
+    for (int k = 0; k < HALF; k++) H0v[k] = 0.0;
+    if constexpr (PF) {
+      if (SP::model(P) == 1) {
+#pragma unroll
+        for (int k = 0; k < HALF; k++) H0v[k] = P.hist_pre[e * NIP + half * HALF + k];
+      }
+    }
+    ElemData<SH, PF> E;
+    gather_elem<SH, PF, SP>(P, cn, E);
+    R.zero();
+#pragma unroll 1
+    for (int k = 0; k < HALF; k++) {
+      const int ip = half * HALF + k, ipo = (half ^ 1) * HALF + k;      // own point, partner's point
+      IpRec<SH, FAM, KEEP> r, rp;
+      double H0 = 0.0;
+#pragma unroll
+      for (int q = 0; q < HALF; q++) if (q == k) H0 = H0v[q];
+      ip_point<SH, FAM, WANT_K, KEEP, SP>(P, e, ip, E, H0, (fl >> (2 + k)) & 1u, r, err_acc);
+      double Nip[NPE];
+#pragma unroll
+      for (int b = 0; b < NPE; b++) Nip[b] = P.tab[ip * NPE + b];
+      accum_rows<SH, FAM, WANT_K, KEEP>(P, r, la, Nip, R);
+      swap_rec<SH, FAM, KEEP>(r, rp);
+#pragma unroll
+      for (int b = 0; b < NPE; b++) Nip[b] = P.tab[ipo * NPE + b];
+      accum_rows<SH, FAM, WANT_K, KEEP>(P, rp, la, Nip, R);
+    }
+  }
+  __syncthreads();
+  if (owner) lds_add_rows<SH, WANT_K, PF, KEEP, true>(P, R, sK, sF, rs0, nnb, aloc * NDOF, ps);
+  __syncthreads();
+  if constexpr (WANT_K) {
+    double* __restrict__ Kg = P.K + base;
+    if (P.overwrite) for (int i = tid; i < len; i += kBlock) Kg[i] = sK[i];
+    else             for (int i = tid; i < len; i += kBlock) Kg[i] += sK[i];
+  }
+  {
+    double* __restrict__ fg = P.f + (int64_t)n0 * NDOF;
+    if (P.overwrite) for (int i = tid; i < nf; i += kBlock) fg[i] = sF[i];
+    else             for (int i = tid; i < nf; i += kBlock) fg[i] += sF[i];
+  }
+  if (PF && P.err_part != nullptr) reduce_err<kBlock>(err_acc, sErr, &P.err_part[tile]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Generic fallback: any dof map, any CSR pattern (searched per entry like MatrixBuilder::addBlock)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int64_t find_col(const Params& P, int64_t row, int64_t col) {
@@ -1099,6 +1244,22 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
       configured = shmem;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SH::PBLOCK), shmem, st, P);
+    }
+  } else if (path == PATH_ROWS_PAIR) {
+    if constexpr (SH::NIP % 2 != 0) return -1000;
+    else {
+      auto go = [&](auto spec) {
+        using SP = decltype(spec);
+        hipLaunchKernelGGL((assemble_rows_pair<SH, FAM, WANT_K, KEEP, SP>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
+      };
+      if constexpr (FAM == FAM_LE) go(SpecFixed<0, 0, 0>{});
+      else if constexpr (FAM == FAM_PF_ISO) {
+        if (P.model == 1 && P.ptype == 0 && P.material == 1) go(SpecFixed<1, 0, 1>{});
+        else go(SpecCanon{});
+      } else {
+        if (P.model == 1 && P.ptype == 0) go(SpecFixed<1, 0, 3>{});
+        else go(SpecCanon{});
+      }
     }
   } else if (path == PATH_ROWS || path == PATH_ROWS_ORDERED) {
     // the common configurations get a kernel with model / exponent / material folded in
