@@ -531,7 +531,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   }
   // ---- pair tiling (row kernel with Gauss points shared by lane pairs; Quad4 / Hex8) ----
   std::vector<int32_t> lrec2, wginfo2;
-  if (rows_ok && nel > 0 && sh.nip % 2 == 0 && !getenv("FA_NO_PAIR")) {
+  if (rows_ok && nel > 0 && sh.nip % 2 == 0 && (rank == 2 || getenv("FA_PAIR_3D")) && !getenv("FA_NO_PAIR")) {   // Hex8: the pair kernel needs > 512 registers, slower
     const int LS = fa::lrec_stride2(npe), HALF = sh.nip / 2;
     // greedy tiles: an element with k nodes in the tile takes 2*ceil(k/2) lanes
     std::vector<int32_t> stamp(nel, -1), cnt_in(nel, 0), tstart;
