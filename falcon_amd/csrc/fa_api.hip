@@ -790,7 +790,22 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
       HIP_TRY(hipMemsetAsync(a->f_int, 0, sizeof(double) * c->ndof, st));
     }
   }
+#ifdef FA_TRACE
+  static void* dbgbuf = nullptr; static int ncall = 0;
+  const size_t dbgbytes = (size_t)std::max(c->ntile2, 1) * 4 * 8 * sizeof(long long);
+  if (!dbgbuf) HIP_TRY(hipMalloc(&dbgbuf, dbgbytes));
+  P.dbg = dbgbuf;
+#endif
   int rc = c->launch(P, c->fam, want_K, keep, path, grid, (void*)st);
+#ifdef FA_TRACE
+  if (++ncall == 6 && getenv("FA_TRACE_FILE")) {
+    std::vector<long long> h(dbgbytes / sizeof(long long));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h.data(), dbgbuf, dbgbytes, hipMemcpyDeviceToHost));
+    FILE* fp = fopen(getenv("FA_TRACE_FILE"), "wb");
+    if (fp) { fwrite(h.data(), 1, dbgbytes, fp); fclose(fp); }
+  }
+#endif
   if (rc == -1000) return fail(FA_ERR_UNSUPPORTED, "kernel family not built for this shape");
   if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   if (want_err) {

@@ -88,6 +88,7 @@ struct Params {
   const double*  hist_pre;
   double*        hist_new;
   double*        strain;     // strain_ cache or nullptr
+  void*          dbg;        // FA_TRACE builds: per-wave phase time stamps
   double*        err_part;   // per-workgroup partial sums of (pf-pfEx)^2 (ExtIt) or nullptr
   double*        K;
   double*        f;

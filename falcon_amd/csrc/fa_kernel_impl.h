@@ -605,12 +605,15 @@ __device__ __forceinline__ void accum_rows(const Params& P, const IpRec<SH, FAM,
     R.fp += wNa * r.cf + P.c2 * gg;                                   // f2 (:728-730)
     if constexpr (WANT_K) {
       const double wc1 = wNa * r.c1;
+      double c2w[RANK];
 #pragma unroll
-      for (int b = 0; b < NPE; b++) {                                 // K4 (:714-716)
-        double gab = 0.0;
+      for (int i = 0; i < RANK; i++) c2w[i] = P.c2 * wga[i];
 #pragma unroll
-        for (int i = 0; i < RANK; i++) gab += wga[i] * r.g[b][i];
-        R.Kpp[b] += wc1 * Nip[b] + P.c2 * gab;
+      for (int b = 0; b < NPE; b++) {                                 // K4 (:714-716): w c1 N N^T + w c2 grad N . grad N
+        double t = R.Kpp[b] + wc1 * Nip[b];
+#pragma unroll
+        for (int i = 0; i < RANK; i++) t += c2w[i] * r.g[b][i];
+        R.Kpp[b] = t;
       }
       if constexpr (KEEP) {
         if (P.keep2) {                                                // K2 += w g' B^T (sigma+ (x) N) (:720)
@@ -776,6 +779,47 @@ __device__ __forceinline__ void lds_add_rows(const Params& P, const RowBlock<SH,
       }
     }
   }
+}
+
+// Stream n doubles of an LDS image to HBM (coalesced, 4 independent LDS reads in flight per lane).
+template <int BLK>
+__device__ __forceinline__ void stream_out(double* __restrict__ g, const double* s, int n, bool overwrite) {
+  int i = threadIdx.x;
+  if (overwrite) {
+    for (; i + 3 * BLK < n; i += 4 * BLK) {
+      const double a0 = s[i], a1 = s[i + BLK], a2 = s[i + 2 * BLK], a3 = s[i + 3 * BLK];
+      g[i] = a0; g[i + BLK] = a1; g[i + 2 * BLK] = a2; g[i + 3 * BLK] = a3;
+    }
+    for (; i < n; i += BLK) g[i] = s[i];
+  } else {
+    for (; i + 3 * BLK < n; i += 4 * BLK) {
+      const double b0 = g[i], b1 = g[i + BLK], b2 = g[i + 2 * BLK], b3 = g[i + 3 * BLK];
+      const double a0 = s[i], a1 = s[i + BLK], a2 = s[i + 2 * BLK], a3 = s[i + 3 * BLK];
+      g[i] = b0 + a0; g[i + BLK] = b1 + a1; g[i + 2 * BLK] = b2 + a2; g[i + 3 * BLK] = b3 + a3;
+    }
+    for (; i < n; i += BLK) g[i] += s[i];
+  }
+}
+
+// Same for the K image with 16-byte accesses: the image sits at s[0..n) with s - (base & 1) 16-byte aligned in LDS
+// and g = K + base, so that element i of the image is 16-byte aligned in LDS exactly when it is in HBM
+// (K itself 16-byte aligned, checked by the caller).  odd = base & 1.
+template <int BLK>
+__device__ __forceinline__ void stream_out16(double* __restrict__ g, const double* s, int n, int odd, bool overwrite) {
+  const int tid = threadIdx.x;
+  if (odd && tid == 0 && n > 0) { if (overwrite) g[0] = s[0]; else g[0] += s[0]; }
+  const int i0 = odd, npair = (n - i0) >> 1;
+  double2* __restrict__ g2 = (double2*)(g + i0);
+  const double2* s2 = (const double2*)(s + i0);
+  int p = tid;
+  if (overwrite) {
+    for (; p + BLK < npair; p += 2 * BLK) { const double2 a0 = s2[p], a1 = s2[p + BLK]; g2[p] = a0; g2[p + BLK] = a1; }
+    for (; p < npair; p += BLK) g2[p] = s2[p];
+  } else {
+    for (; p < npair; p += BLK) { double2 b = g2[p]; const double2 a = s2[p]; b.x += a.x; b.y += a.y; g2[p] = b; }
+  }
+  const int last = i0 + 2 * npair;
+  if (last < n && tid == BLK - 1) { if (overwrite) g[last] = s[last]; else g[last] += s[last]; }
 }
 
 template <int BLOCKSZ>
@@ -997,16 +1041,8 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
     __syncthreads();
   }
 
-  if constexpr (WANT_K) {
-    double* __restrict__ Kg = P.K + base;
-    if (P.overwrite) for (int i = tid; i < len; i += kBlock) Kg[i] = sK[i];
-    else             for (int i = tid; i < len; i += kBlock) Kg[i] += sK[i];
-  }
-  {
-    double* __restrict__ fg = P.f + (int64_t)n0 * NDOF;
-    if (P.overwrite) for (int i = tid; i < nf; i += kBlock) fg[i] = sF[i];
-    else             for (int i = tid; i < nf; i += kBlock) fg[i] += sF[i];
-  }
+  if constexpr (WANT_K) stream_out<kBlock>(P.K + base, sK, len, P.overwrite);
+  stream_out<kBlock>(P.f + (int64_t)n0 * NDOF, sF, nf, P.overwrite);
   if (PF && P.err_part != nullptr) reduce_err<kBlock>(err_acc, sErr, &P.err_part[tile]);
 }
 
@@ -1023,8 +1059,10 @@ template <class T>
 __device__ __forceinline__ T pair_swap(T v) {
   static_assert(sizeof(T) == 8, "doubles");
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+  // quad_perm [1,0,3,2]; bound_ctrl + no "old" operand: every lane of an active pair reads its active partner, so
+  // the destination needs no initialisation
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 
@@ -1066,11 +1104,14 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows_pair(const Params P) 
   constexpr bool PF = (FAM != FAM_LE);
   constexpr int NDOF = PF ? RANK + 1 : RANK;
   static_assert(NIP % 2 == 0, "pairs split the Gauss points in halves");
-  __shared__ double sK[WANT_K ? kLdsDoubles : 1];
+  __shared__ __attribute__((aligned(16))) double sKbuf[WANT_K ? kLdsDoubles + 2 : 2];
   __shared__ double sF[kBlock * NDOF];
   __shared__ double sErr[kBlock / 64];
 
   const int tid = threadIdx.x;
+#ifdef FA_TRACE
+  long long tr[8]; tr[0] = __builtin_readcyclecounter();
+#endif
   const int per = (int)gridDim.x >> 3;                 // XCD bands as in assemble_rows
   const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
   if (tile >= P.ntile2) return;
@@ -1079,6 +1120,8 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows_pair(const Params P) 
   const int64_t t0 = ((int64_t)(uint32_t)wi[2]) | ((int64_t)wi[7] << 32);
   const int64_t base = ((int64_t)(uint32_t)wi[4]) | ((int64_t)wi[5] << 32);
   const int len = WANT_K ? wi[6] : 0;
+  const int odd = (int)(base & 1);                     // image shifted by one double when K + base is not 16-byte aligned
+  double* sK = sKbuf + odd;
   const int nf = (n1 - n0) * NDOF;
   const bool active = tid < nlane;                     // nlane is even: pairs are active together
   constexpr int LS = lrec_stride2(NPE);
@@ -1120,6 +1163,10 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows_pair(const Params P) 
     }
     ElemData<SH, PF> E;
     gather_elem<SH, PF, SP>(P, cn, E);
+#ifdef FA_TRACE
+    if (E.x[0][0] + E.u[3][1] + H0v[0] == 1.234e300) err_acc = 1.0;     // wait for the gathers
+    tr[1] = __builtin_readcyclecounter();
+#endif
     R.zero();
 #pragma unroll 1
     for (int k = 0; k < HALF; k++) {
@@ -1139,19 +1186,35 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows_pair(const Params P) 
       accum_rows<SH, FAM, WANT_K, KEEP>(P, rp, la, Nip, R);
     }
   }
+#ifdef FA_TRACE
+  tr[2] = __builtin_readcyclecounter();
+#endif
   __syncthreads();
+#ifdef FA_TRACE
+  tr[3] = __builtin_readcyclecounter();
+#endif
   if (owner) lds_add_rows<SH, WANT_K, PF, KEEP, true>(P, R, sK, sF, rs0, nnb, aloc * NDOF, ps);
+#ifdef FA_TRACE
+  tr[6] = __builtin_readcyclecounter();
+#endif
   __syncthreads();
+#ifdef FA_TRACE
+  tr[7] = __builtin_readcyclecounter();
+#endif
   if constexpr (WANT_K) {
-    double* __restrict__ Kg = P.K + base;
-    if (P.overwrite) for (int i = tid; i < len; i += kBlock) Kg[i] = sK[i];
-    else             for (int i = tid; i < len; i += kBlock) Kg[i] += sK[i];
+    if ((((uintptr_t)P.K) & 15) == 0) stream_out16<kBlock>(P.K + base, sK, len, odd, P.overwrite);
+    else stream_out<kBlock>(P.K + base, sK, len, P.overwrite);
   }
-  {
-    double* __restrict__ fg = P.f + (int64_t)n0 * NDOF;
-    if (P.overwrite) for (int i = tid; i < nf; i += kBlock) fg[i] = sF[i];
-    else             for (int i = tid; i < nf; i += kBlock) fg[i] += sF[i];
+  stream_out<kBlock>(P.f + (int64_t)n0 * NDOF, sF, nf, P.overwrite);
+#ifdef FA_TRACE
+  tr[4] = __builtin_readcyclecounter();
+  __builtin_amdgcn_s_waitcnt(0);
+  tr[5] = __builtin_readcyclecounter();
+  if ((tid & 63) == 0 && P.dbg != nullptr) {
+    long long* out = (long long*)P.dbg + ((int64_t)tile * 4 + (tid >> 6)) * 8;
+    out[0] = tr[0]; out[1] = tr[1]; out[2] = tr[2]; out[3] = tr[3]; out[4] = tr[6]; out[5] = tr[7]; out[6] = tr[4]; out[7] = tr[5];
   }
+#endif
   if (PF && P.err_part != nullptr) reduce_err<kBlock>(err_acc, sErr, &P.err_part[tile]);
 }
 
