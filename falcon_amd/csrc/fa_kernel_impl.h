@@ -1139,6 +1139,7 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
   if constexpr (WANT_K)
     for (int i = tid; i < len; i += kBlock) sK[i] = 0.0;
   for (int i = tid; i < nf; i += kBlock) sF[i] = 0.0;
+  __syncthreads();                                     // image zeroed: from here every wave adds as soon as it has computed
 
   RowBlock<SH, WANT_K, PF, KEEP> R;
   int32_t cn[NPE];
@@ -1193,10 +1194,7 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
   }
 #ifdef FA_TRACE
   tr[2] = __builtin_readcyclecounter();
-#endif
-  __syncthreads();
-#ifdef FA_TRACE
-  tr[3] = __builtin_readcyclecounter();
+  tr[3] = tr[2];
 #endif
   if (owner) lds_add_rows<SH, WANT_K, PF, KEEP, true>(P, R, sK, sF, rs0, nnb, aloc * NDOF, ps);
 #ifdef FA_TRACE
