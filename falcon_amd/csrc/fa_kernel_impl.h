@@ -1101,7 +1101,7 @@ __device__ __forceinline__ void swap_rec(const IpRec<SH, FAM, KEEP>& m, IpRec<SH
 // two waves per SIMD (256 registers): the variants with off-diagonal blocks would otherwise take 270+ registers and
 // run at one wave per SIMD; a few spilled values cost less than the lost overlap
 #ifndef FA_PAIR_ATTR
-#define FA_PAIR_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#define FA_PAIR_ATTR __attribute__((amdgpu_waves_per_eu(2)))
 #endif
 template <class SH, int FAM, bool WANT_K, bool KEEP, class SP>
 __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(const Params P) {
