@@ -149,7 +149,11 @@ class Assembler:
             lib().fa_destroy(self.h)
             self.h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except TypeError:      # interpreter shutdown: module globals are already gone
+            pass
 
     def pattern(self):
         rp = np.empty(self.ndof + 1, dtype=np.int64); ci = np.empty(self.nnz, dtype=np.int32)
