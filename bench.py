@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--material", default="amor", choices=["amor", "miehe", "bourdin"])
     ap.add_argument("--keep-off-diags", action="store_true")
     ap.add_argument("--force-only", action="store_true", help="GET_INT_VECTOR pass instead of GET_MATRIX0")
-    ap.add_argument("--cpu-elems", type=int, default=2250000, help="elements in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-elems", type=int, default=6250000, help="elements in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch
