@@ -326,3 +326,54 @@ def test_high_order_ext_models_and_column_search(shape):
     run_both(shape, capi.PHASE_FRACTURE_EXT, capi.AMOR_PHASE)
     run_both(shape, capi.PHASE_FRACTURE_EXTIT, capi.MIEHE_PHASE, flags=capi.ACCUMULATE)
     run_both(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, keep=1, flags=capi.OVERWRITE | capi.FORCE_GENERIC)
+
+
+def test_full_size_invariants_cfg3():
+    """BASELINE config 3 at its full size (4000 x 4000 Q4, u-phi, AT2, Amor): too large for the oracle, so the result
+    is checked through size-independent properties of the discretisation:
+      * sum_a B_a = 0 (partition of unity)  =>  the internal forces of every displacement component sum to zero,
+        and a rigid translation is in the null space of the u-u block: every u row of K sums to zero over the
+        u columns of the same component pair;
+      * K4 row sums: sum_b K_phi_phi[a,b] = int N_a (gc/l0 * ddw/cw... + g'' Psi) dV > 0 and symmetric u-u block;
+      * the force-only call returns the same f_int as the matrix call, and the history is written identically;
+      * FA_ACCUMULATE on a zeroed K equals FA_OVERWRITE."""
+    import torch
+    n = 4000
+    coords, conn = meshgen.grid_quad4(n, n)
+    kw = dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=False)
+    asm = capi.Assembler(capi.QUAD4_G2, capi.PHASE_FRACTURE, capi.AMOR_PHASE, coords, conn, **kw)
+    dev = torch.device("cuda", 0)
+    st = torch.from_numpy(meshgen.smooth_state(coords, 3)).to(dev)
+    del coords
+    K = torch.empty(asm.nnz, dtype=torch.float64, device=dev).fill_(float("nan"))
+    f = torch.empty(asm.ndof, dtype=torch.float64, device=dev).fill_(float("nan"))
+    asm.assemble(st, K, f, flags=capi.OVERWRITE)
+    torch.cuda.synchronize()
+    assert not torch.isnan(K).any() and not torch.isnan(f).any()                 # every entry of the pattern was written
+    fmax = f.abs().max().item()
+    for c in range(2):
+        assert abs(f[c::3].sum().item()) < 1e-9 * fmax * np.sqrt(asm.ndof)
+    # row sums per column type: the pattern is blocked [neighbour][type], 3 entries per neighbour in every row
+    Kb = K.view(-1, 3)                                                           # (row-entry groups, column type)
+    rp = torch.from_numpy(asm.pattern()[0]).to(dev)
+    grp = rp // 3
+    cs = torch.zeros(Kb.shape[0] + 1, 3, dtype=torch.float64, device=dev)
+    torch.cumsum(Kb, 0, out=cs[1:])
+    rowsum = cs[grp[1:]] - cs[grp[:-1]]                                          # (ndof, 3): sum over neighbours per column type
+    kmax = K.abs().max().item()
+    urows = torch.arange(asm.ndof, device=dev) % 3 < 2
+    assert rowsum[urows][:, :2].abs().max().item() < 1e-7 * kmax                 # translation null space (cumsum rounding)
+    assert rowsum[urows][:, 2].abs().max().item() == 0.0                         # u-phi block not written: exact zeros
+    assert rowsum[~urows][:, :2].abs().max().item() == 0.0                       # phi-u block not written
+    assert rowsum[~urows][:, 2].min().item() > 0.0                               # K4 row sums are positive
+    del cs, rowsum, Kb
+    h1 = asm.get_history(1).copy()
+    f2 = torch.zeros_like(f)
+    asm.assemble(st, None, f2, flags=capi.OVERWRITE)
+    torch.cuda.synchronize()
+    assert torch.equal(f, f2) or (f - f2).abs().max().item() < 1e-13 * fmax
+    assert np.array_equal(asm.get_history(1), h1)
+    K2 = torch.zeros_like(K); f3 = torch.zeros_like(f)
+    asm.assemble(st, K2, f3, flags=capi.ACCUMULATE)
+    torch.cuda.synchronize()
+    assert (K - K2).abs().max().item() < 1e-12 * kmax and (f - f3).abs().max().item() < 1e-12 * fmax
