@@ -1174,7 +1174,10 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
     tr[1] = __builtin_readcyclecounter();
 #endif
     R.zero();
-#pragma unroll 1
+#ifndef FA_PAIR_UNROLL
+#define FA_PAIR_UNROLL 2
+#endif
+#pragma unroll FA_PAIR_UNROLL
     for (int k = 0; k < HALF; k++) {
       const int ip = half * HALF + k, ipo = (half ^ 1) * HALF + k;      // own point, partner's point
       IpRec<SH, FAM, KEEP> r, rp;
