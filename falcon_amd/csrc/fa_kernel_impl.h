@@ -975,7 +975,7 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, kBlock = SH::BLOCK, kLdsDoubles = SH::LDS;
   constexpr bool PF = (FAM != FAM_LE);
   constexpr int NDOF = PF ? RANK + 1 : RANK;
-  __shared__ double sK[WANT_K ? kLdsDoubles : 1];
+  __shared__ __attribute__((aligned(16))) double sKbuf[WANT_K ? kLdsDoubles + 2 : 2];
   __shared__ double sF[kBlock * NDOF];
   __shared__ double sErr[kBlock / 64];
 
@@ -993,6 +993,8 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
   const int32_t* __restrict__ wi = P.wginfo + (int64_t)tile * kWgInfo;
   const int n0 = wi[0], n1 = wi[1], t0 = wi[2], nlane = wi[3];
   const int64_t base = ((int64_t)(uint32_t)wi[4]) | ((int64_t)wi[5] << 32);
+  const int odd = (int)(base & 1);                     // image shifted by one double when K + base is not 16-byte aligned
+  double* sK = sKbuf + odd;
   const int len = WANT_K ? wi[6] : 0;
   const int nf = (n1 - n0) * NDOF;
   const bool active = tid < nlane;
@@ -1041,7 +1043,10 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
     __syncthreads();
   }
 
-  if constexpr (WANT_K) stream_out<kBlock>(P.K + base, sK, len, P.overwrite);
+  if constexpr (WANT_K) {
+    if ((((uintptr_t)P.K) & 15) == 0) stream_out16<kBlock>(P.K + base, sK, len, odd, P.overwrite);
+    else stream_out<kBlock>(P.K + base, sK, len, P.overwrite);
+  }
   stream_out<kBlock>(P.f + (int64_t)n0 * NDOF, sF, nf, P.overwrite);
   if (PF && P.err_part != nullptr) reduce_err<kBlock>(err_acc, sErr, &P.err_part[tile]);
 }
