@@ -1179,10 +1179,10 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
     tr[1] = __builtin_readcyclecounter();
 #endif
     R.zero();
-#ifndef FA_PAIR_UNROLL
-#define FA_PAIR_UNROLL 2
-#endif
-#pragma unroll FA_PAIR_UNROLL
+    // the matrix kernels of the isotropic phase-field family gain from both points in flight (more ILP and, as it
+    // happens, fewer registers); the force-only, elastic and Miehe kernels are faster with the loop rolled
+    constexpr int kUnroll = (WANT_K && FAM == FAM_PF_ISO) ? 2 : 1;
+#pragma unroll kUnroll
     for (int k = 0; k < HALF; k++) {
       const int ip = half * HALF + k, ipo = (half ^ 1) * HALF + k;      // own point, partner's point
       IpRec<SH, FAM, KEEP> r, rp;
