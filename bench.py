@@ -80,10 +80,32 @@ def cpu_baseline(wl, capi, meshgen, target_elems):
     rp, ci = po.pattern(coords.shape[0], conn, nd, rank)
     st = meshgen.smooth_state(coords, nd)
     t = time.perf_counter()
-    po.assemble(cfg, coords, conn, rp, ci, st)
+    ref = po.assemble(cfg, coords, conn, rp, ci, st)
     dt = time.perf_counter() - t
-    return dict(value=conn.shape[0] / dt, unit="elements/s", cores=1, kind="port", sample=sample,
-                seconds=round(dt, 2))
+    one = dict(value=conn.shape[0] / dt, unit="elements/s", cores=1, kind="port", sample=sample, seconds=round(dt, 2))
+    # the same loop on all the host cores this job may use: element-block strips in two colours (strips of one colour
+    # share no node), one thread per strip -- SURVEY.md 8d asks for it next to the 1-core figure
+    import concurrent.futures as cf
+    cores = min(16, len(os.sched_getaffinity(0)))
+    nel = conn.shape[0]
+    per_row = m if rank == 2 else m * m                 # elements per mesh row (2D) / slab (3D)
+    nstrip = min(2 * cores, m // 2)
+    if cores < 2 or nstrip < 4:
+        return one, None
+    rows = [m * k // nstrip for k in range(nstrip + 1)]
+    K = np.zeros(rp[-1]); f = np.zeros(ref["f"].size)
+    hn = np.zeros_like(ref["hist_new"]) if ref["hist_new"] is not None else None
+    def run(k):
+        po.assemble(cfg, coords, conn, rp, ci, st, K=K, f=f, hist_new=hn, el_range=(rows[k] * per_row, rows[k + 1] * per_row))
+    t = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        for colour in (0, 1):
+            list(ex.map(run, range(colour, nstrip, 2)))
+    dtm = time.perf_counter() - t
+    assert np.abs(K - ref["K"]).max() <= 1e-12 * np.abs(ref["K"]).max()
+    allc = dict(value=nel / dtm, unit="elements/s", cores=cores, kind="port",
+                sample=sample + f"; {nstrip} element strips in two colours on {cores} threads", seconds=round(dtm, 2))
+    return one, allc
 
 
 def main():
@@ -211,7 +233,9 @@ def main():
                          "algorithmic_bytes_per_launch": ab, "bytes_per_element": ab / asm.nel},
         }
         if world == 1 and args.cpu_elems > 0:
-            out["cpu_baseline"] = cpu_baseline(wl, capi, meshgen, args.cpu_elems)
+            out["cpu_baseline"], allc = cpu_baseline(wl, capi, meshgen, args.cpu_elems)
+            if allc is not None:
+                out["cpu_baseline_all_cores"] = allc
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -139,7 +139,7 @@ def pattern(nnode, conn, ndofpn, rank, kind=PATTERN_FULL, keep=0):
 
 
 def assemble(cfg, coords, conn, row_ptr, col_idx, state, state0=None, state00=None, dt=0.0, dt0=0.0,
-             hist_pre=None, want_K=True, want_strain=False, K=None, f=None, el_range=None):
+             hist_pre=None, want_K=True, want_strain=False, K=None, f=None, el_range=None, hist_new=None):
     """One GET_MATRIX0 (want_K) / GET_INT_VECTOR pass.  Returns dict(K, f, hist_new, strain, err_ext).
     For ExtIt pass stateExt_ as state00."""
     coords = np.ascontiguousarray(coords, dtype=np.float64)
@@ -155,12 +155,14 @@ def assemble(cfg, coords, conn, row_ptr, col_idx, state, state0=None, state00=No
         K = np.zeros(row_ptr[-1])
     if f is None:
         f = np.zeros(ndof)
-    hist_new = None
     if cfg.model == PHASE_FRACTURE:
         if hist_pre is None:
             hist_pre = np.full(nel * nip, psi0(cfg))
         hist_pre = np.ascontiguousarray(hist_pre, dtype=np.float64)
-        hist_new = np.zeros(nel * nip)
+        if hist_new is None:
+            hist_new = np.zeros(nel * nip)
+    else:
+        hist_new = None
     srows = strc + (0 if cfg.model == LINEAR_ELASTICITY else 1)
     strain = np.zeros((nel * nip, srows)) if want_strain else None
     err = C.c_double(0.0)
