@@ -1,25 +1,22 @@
 // fa_kernel_impl.h -- gfx950 kernels for the element-level K / f_int assembly.
 //
-// Three kernels share one Gauss-point core (ip_point / accum_rows):
+// The kernels share one Gauss-point core (ip_point / ip_material / accum_rows):
 //
-//  assemble_patch  (opt-in, FA_USE_PATCH; experimental)  "owner computes" on 2-D/3-D node patches.  A workgroup owns a compact set
-//      of nodes; the slice of the CSR value array that holds their rows is mirrored in LDS.  Every
-//      element touching the patch gets a group of NPE adjacent lanes (lane la <-> local node la).  When
-//      NIP == NPE the group shares the Gauss-point work: lane la evaluates Gauss point la (Jacobian,
-//      gradients, strain, degradation, material update, history) and broadcasts that record inside the
-//      group with DPP quad permutes (NPE == 4) or ds_bpermute; each lane then keeps only the rows of its
-//      own node of K1..K4 / f1,f2 (PhaseFractureModel.cpp:713-730) and adds them into the LDS image with
-//      ds_add_f64.  Lanes whose node belongs to another patch only help with the Gauss points.  The LDS
-//      image is streamed to HBM in runs of consecutive nodes: coalesced, every K entry written once, no
-//      global atomics.
-//  assemble_rows   (default)  one lane per (node, incident element) pair on contiguous node ranges: the
-//      lane evaluates the element's Gauss points and keeps the rows of its node; the workgroup's rows are one
-//      contiguous slice of the CSR value array, mirrored in LDS, filled with ds_add_f64 and streamed out with
-//      coalesced stores.  With FA_DETERMINISTIC the lanes add in phases ordered by the element's slot in the
-//      node's element list instead, so every CSR entry is summed in ascending element order like the
-//      reference's serial loop (bitwise reproducible).
+//  assemble_rows_pair  (default for Quad4)  "owner computes" on tiles of consecutive nodes: the slice of the CSR value
+//      array that holds the tile's rows is mirrored in LDS.  Lanes come in aligned pairs working on one element;
+//      each evaluates half of the Gauss points (Jacobian, gradients, strain, degradation, material update, history),
+//      the two swap every Gauss-point record with a DPP quad permute and each keeps only the rows of its own node
+//      of K1..K4 / f1,f2 (PhaseFractureModel.cpp:713-730).  Row blocks go into the LDS image with ds_add_f64; the
+//      image is streamed to HBM with 16-byte coalesced stores: every K entry written once, no global atomics.
+//  assemble_rows   (Triangle3, Hex8; FA_DETERMINISTIC)  same tiles, one lane per (node, incident element) pair
+//      evaluating all Gauss points.  With FA_DETERMINISTIC the lanes add in phases ordered by the element's slot in
+//      the node's element list, so every CSR entry is summed in ascending element order like the reference's
+//      serial loop (bitwise reproducible).
 //  assemble_generic  any dof map / any CSR pattern: per-entry column search + FP64 atomics, like
 //      MatrixBuilder::addBlock.
+//  assemble_patch  (opt-in, FA_USE_PATCH; experimental)  2-D/3-D node patches, NPE lanes per element sharing the
+//      Gauss points; correct but slower than the row kernels.
+//  (fa_coop_impl.h: assemble_coop for the higher-order shapes.)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -980,11 +977,6 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
   __shared__ double sErr[kBlock / 64];
 
   const int tid = threadIdx.x;
-#if defined(FA_STAGGER)
-  // experiment: offset the phases of the workgroups that share a CU
-  if (FA_STAGGER_COND) { for (int k = 0; k < FA_STAGGER; k++) __builtin_amdgcn_s_sleep(127); }
-#endif
-  // workgroup descriptor: one scalar load instead of the wg_start -> n2e_ptr / row_ptr chain
   // blockIdx % 8 is the XCD: give every XCD one contiguous band of tiles, so that the tile rows that gather the
   // same nodes meet in one L2
   const int per = (int)gridDim.x >> 3;                 // the grid is a multiple of 8
