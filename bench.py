@@ -7,7 +7,7 @@ over the whole synthetic mesh, inputs resident in HBM.  N=1 workload = BASELINE.
 scaling, one 4000x(4000) strip per GPU stacked in y, interface f_int entries summed with the
 neighbouring ranks over RCCL (falcon_amd/distributed.py); value = all ranks' elements / max time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5|cfg5g2] [--n SIZE]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5|cfg5g2|cfg3micro] [--n SIZE]
                     [--material amor|miehe|bourdin] [--keep-off-diags] [--mode ...] [--pattern ...] [--force-only]
 """
 import argparse
@@ -44,6 +44,14 @@ def workload(name, n, capi, material="amor", keep=False):
                          f"keepOffDiags={'true' if keep else 'false'}", shape=capi.QUAD4_G2, model=capi.PHASE_FRACTURE,
                     material=mat, dims=(n, n), h=1.0 / n, written_per_pair=9 if keep else 5,
                     kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=keep))
+    if name == "cfg3micro":      # the micromorphic variant on the cfg3 mesh (Miehe / Bourdin, penalty 250)
+        n = n or 4000
+        m2 = capi.BOURDIN_PHASE if material == "bourdin" else capi.MIEHE_PHASE
+        return dict(desc=f"cfg3micro: {n}x{n} Q4, MicroPhaseFracture (u-phi, local damage by Newton), AT2, "
+                         f"{'BourdinPhase' if material == 'bourdin' else 'MiehePhase'}, keepOffDiags={'true' if keep else 'false'}",
+                    shape=capi.QUAD4_G2, model=capi.MICRO_PHASE_FRACTURE, material=m2, dims=(n, n), h=1.0 / n,
+                    written_per_pair=9 if keep else 5,
+                    kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=keep, beta=250.0))
     if name == "cfg4":
         n = n or 200
         return dict(desc=f"cfg4: {n}^3 hex8 phase-field fracture cube, AT2, {mname}", shape=capi.HEX8_G2,
@@ -75,7 +83,7 @@ def cpu_baseline(wl, capi, meshgen, target_elems):
     kw = dict(wl["kw"])
     cfg = po.make_config(wl["shape"], wl["model"], wl["material"], young=kw["young"], poisson=kw["poisson"],
                          gc=kw.get("gc", 2.7), l0=kw.get("l0", 0.015), frac_type=kw.get("frac_type", 1),
-                         keep_off_diags=int(kw.get("keep_off_diags", False)))
+                         keep_off_diags=int(kw.get("keep_off_diags", False)), beta=kw.get("beta", 6500.0))
     nd = po.ndof_per_node(wl["model"], rank)
     rp, ci = po.pattern(coords.shape[0], conn, nd, rank)
     st = meshgen.smooth_state(coords, nd)

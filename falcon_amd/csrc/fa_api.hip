@@ -292,7 +292,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     return fail(FA_ERR_ARG, "unknown shape id %d", p->shape);
   c->launch = launcher_for(p->shape);
   c->rank = sh.rank; c->npe = sh.npe; c->nip = sh.nip; c->str = (sh.rank == 2) ? 4 : 6;
-  if (p->model < FA_LINEAR_ELASTICITY || p->model > FA_PHASE_FRACTURE_EXTIT) return fail(FA_ERR_ARG, "invalid model %d", p->model);
+  if (p->model < FA_LINEAR_ELASTICITY || p->model > FA_MICRO_PHASE_FRACTURE) return fail(FA_ERR_ARG, "invalid model %d", p->model);
   const bool pf = p->model != FA_LINEAR_ELASTICITY;
   c->ndofpn = pf ? sh.rank + 1 : sh.rank;
   c->srows = pf ? c->str + 1 : c->str;
@@ -301,6 +301,12 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   if (pf && p->material == FA_HOOKE) return fail(FA_ERR_ARG, "phase-field models need a PhaseFractureMaterial");
   if (p->material < FA_HOOKE || p->material > FA_MIEHE_PHASE) return fail(FA_ERR_ARG, "Invalid material: %d", p->material);
   c->fam = !pf ? fa::FAM_LE : (p->material == FA_MIEHE_PHASE ? fa::FAM_PF_MIEHE : fa::FAM_PF_ISO);
+  if (p->model == FA_MICRO_PHASE_FRACTURE) {
+    // AmorPhase's split update leaves stiffN untouched in tension (AmorPhaseMaterial.cpp:239-268), so the reference's
+    // result depends on what an earlier Gauss point of its serial loop left there: not reproducible in parallel
+    if (p->material == FA_AMOR_PHASE) return fail(FA_ERR_UNSUPPORTED, "MicroPhaseFracture with AmorPhase depends on the serial Gauss-point order of the reference (stale stiffN); not available on the device");
+    c->fam = fa::FAM_PF_MIEHE;                          // general-tangent family (rank-one term of elemMat1)
+  }
   if (sh.rank == 2 && p->state != FA_PLANE_STRAIN && p->state != FA_PLANE_STRESS)
     return fail(FA_ERR_ARG, "unexpected rank/state");     // HookeMaterial.cpp:262-265
   if (p->nnode <= 0 || p->nel < 0 || !p->coords || (!p->conn && p->nel)) return fail(FA_ERR_ARG, "empty mesh arrays");
@@ -335,6 +341,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     P.ptype = (pe == 2.0) ? 0 : (pe == 2.5 ? 1 : 2);
     P.gcl = gc / (cw * l0); P.c2 = 2.0 * gc * l0 / cw;
     P.eta = eta; P.a1 = a1; P.a2 = a2; P.a3 = a3; P.psi0 = psi0; P.beta = p->beta;
+    P.alpha = p->beta * gc / l0;
     // elastic constants (AmorPhaseMaterial.cpp:85-86, MiehePhaseMaterial.cpp:97-99, HookeMaterial.cpp:202-267)
     const double nu = p->poisson;
     P.Kb = E / (3.0 * (1.0 - 2.0 * nu)); P.G = E / (2.0 * (1.0 + nu)); P.lmda = P.Kb - 0.666666667 * P.G;
@@ -347,8 +354,9 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     }
   }
   P.model = p->model; P.material = p->material; P.ndofpn = nd; P.nnode = nnode; P.nel = nel;
-  P.keep2 = (p->model == FA_PHASE_FRACTURE) && p->keep_off_diags;
-  P.keep3 = (p->model == FA_PHASE_FRACTURE) ? (p->keep_off_diags != 0) : (pf ? 1 : 0);
+  const bool plain = p->model == FA_PHASE_FRACTURE || p->model == FA_MICRO_PHASE_FRACTURE;
+  P.keep2 = plain && p->keep_off_diags;
+  P.keep3 = plain ? (p->keep_off_diags != 0) : (pf ? 1 : 0);
 
   // ---- inverse connectivity, element-ascending per node ----
   std::vector<int32_t> n2e_ptr(nnode + 1, 0), n2e_ent((size_t)nel * npe);
@@ -675,10 +683,10 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     if ((st = upload(&c->d_tab, tab.data(), tab.size()))) return st;
   }
   const int64_t nipt = nel * sh.nip;
-  if (p->model == FA_PHASE_FRACTURE) {
+  if (p->model == FA_PHASE_FRACTURE || p->model == FA_MICRO_PHASE_FRACTURE) {
     for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void**)&c->d_hist[k], std::max<int64_t>(nipt, 1) * sizeof(double)));
     // preHist_.H0_ = Psi0_; newHist_.H0_ = 0 (PhaseFractureModel.cpp:359-360)
-    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[0], nipt, P.psi0);
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[0], nipt, p->model == FA_PHASE_FRACTURE ? P.psi0 : 0.0);   // preHist_.phasef_ = 0 (MicroPhaseFractureModel.cpp:359)
     hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[1], nipt, 0.0);
   }
   if (p->model == FA_PHASE_FRACTURE_EXTIT)
@@ -747,7 +755,7 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   if (!c || !a) return fail(FA_ERR_ARG, "null argument");
   if (!a->state || !a->f_int) return fail(FA_ERR_ARG, "state and f_int are required");
   const int model = c->prob.model;
-  if (model >= FA_PHASE_FRACTURE_EXT && (!a->state0 || !a->state00))
+  if ((model == FA_PHASE_FRACTURE_EXT || model == FA_PHASE_FRACTURE_EXTIT) && (!a->state0 || !a->state00))
     return fail(FA_ERR_ARG, "PhaseFractureExt/ExtIt need state0 and state00 (stateExt_)");
   // LinearElasticityModel answers GET_MATRIX0 only (LinearElasticityModel.cpp:226-246); force-only is still
   // served here because the kernel supports it.
@@ -858,7 +866,7 @@ extern "C" fa_status fa_assemble_host(fa_ctx* c, const double* state, const doub
 
 extern "C" fa_status fa_commit(fa_ctx* c) {
   if (!c) return fail(FA_ERR_ARG, "null argument");
-  if (c->prob.model == FA_PHASE_FRACTURE) std::swap(c->d_hist[0], c->d_hist[1]);
+  if (c->prob.model == FA_PHASE_FRACTURE || c->prob.model == FA_MICRO_PHASE_FRACTURE) std::swap(c->d_hist[0], c->d_hist[1]);
   return FA_OK;
 }
 

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
     if constexpr (PF) {
       const int64_t dp = dof(n, RANK);
       L.phi[a] = P.state[dp];
-      if (P.model >= 2) { L.phi0[a] = P.state0[dp]; L.phiX[a] = P.stateX[dp]; }
+      if (P.model == 2 || P.model == 3) { L.phi0[a] = P.state0[dp]; L.phiX[a] = P.stateX[dp]; }
     }
   }
   __syncthreads();
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
         pf += Na * ph;
 #pragma unroll
         for (int i = 0; i < RANK; i++) gphi[i] += ga[i] * ph;
-        if (P.model >= 2) { pf0 += Na * L.phi0[a]; pfX += Na * L.phiX[a]; }
+        if (P.model == 2 || P.model == 3) { pf0 += Na * L.phi0[a]; pfX += Na * L.phiX[a]; }
       }
     }
     const int64_t ipoint = e * NIP + ip;               // initializeIPMPMap_, PhaseFractureModel.cpp:1070-1093
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
     }
     double H0 = 0.0;
     if constexpr (PF) {
-      if (P.model == 1) H0 = P.hist_pre[ipoint];
+      if (P.model == 1 || P.model == 4) H0 = P.hist_pre[ipoint];
 #pragma unroll
       for (int i = 0; i < RANK; i++) L.gphi[ip][i] = gphi[i];
     }

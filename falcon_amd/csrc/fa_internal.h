@@ -102,6 +102,7 @@ struct Params {
   double hd0, hd1, hd3;      // Hooke D: normal diagonal, normal off-diagonal, shear
   double gcl, c2;            // gc/(cw*l0), 2*gc*l0/cw
   double eta, a1, a2, a3, psi0, beta, dt, dt0;
+  double alpha;              // micromorphic penalty beta * gc / l0 (MicroPhaseFractureModel.cpp:579)
 };
 
 // launchers, one translation unit per shape (fa_kernels_<shape>.hip)

@@ -138,7 +138,7 @@ __device__ __forceinline__ void gather_elem(const Params& P, const int32_t (&cn)
     for (int i = 0; i < RANK; i++) { E.x[a][i] = P.coords[n * RANK + i]; E.u[a][i] = P.state[dofs[i]]; }
     if constexpr (PF) {
       E.phi[a] = P.state[dofs[RANK]];
-      if (SP::model(P) >= 2) { E.phi0[a] = P.state0[dofs[RANK]]; E.phiX[a] = P.stateX[dofs[RANK]]; }
+      if (SP::model(P) == 2 || SP::model(P) == 3) { E.phi0[a] = P.state0[dofs[RANK]]; E.phiX[a] = P.stateX[dofs[RANK]]; }
       else { E.phi0[a] = 0.0; E.phiX[a] = 0.0; }
     }
   }
@@ -242,9 +242,11 @@ __device__ __forceinline__ void jacobi_rot(double (&a)[3][3], double (&V)[3][3])
 // so tensor2voigt(P+) = sum d_a m_a m_a^T + sum theta_ab s_ab s_ab^T with the Voigt vectors of M_a, S_ab.
 // 2D: the strain tensor has no z entries; the z eigen-direction (eigenvalue 0, d = 0) only feeds zz / out-of-plane
 // shear entries, which B never touches, so the in-plane 2x2 problem is solved.
-template <int RANK, int S>
-__device__ __forceinline__ void miehe_update(const Params& P, const double (&e)[S], double g, double (&D)[S][S],
-                                             double (&sig)[S], double (&sp)[S], double& Psi) {
+// gfun(Psi, sigma+) supplies the degradation value once the g-independent part is known (a constant for the
+// PhaseFracture models, the local Newton iteration of the micromorphic model).
+template <int RANK, int S, class GF>
+__device__ __forceinline__ void miehe_update_f(const Params& P, const double (&e)[S], GF&& gfun, double (&D)[S][S],
+                                               double (&sig)[S], double (&sp)[S], double& Psi) {
   constexpr int N = RANK;
   constexpr int VI[6] = { 0, 1, 2, 0, 1, 2 }, VJ[6] = { 0, 1, 2, 1, 2, 0 };   // 3D Voigt: xx yy zz xy yz zx
   auto vi = [&](int I) { return (RANK == 2) ? (I == 2 ? 0 : I) : VI[I]; };
@@ -323,11 +325,13 @@ __device__ __forceinline__ void miehe_update(const Params& P, const double (&e)[
   for (int I = 0; I < S; I++) dd += ((I < N) ? 1.0 : 2.0) * (spos[I] * spos[I]);
   Psi = 0.5 * P.lmda * (trP * trP) + P.G * dd;
 #pragma unroll
+  for (int I = 0; I < S; I++) sp[I] = ((I < N) ? P.lmda * trP : 0.0) + 2.0 * P.G * spos[I];
+  const double g = gfun(Psi, sp);
+#pragma unroll
   for (int I = 0; I < S; I++) {
     const double T = (I < N) ? e[I] : 0.5 * e[I];
-    const double vP = ((I < N) ? P.lmda * trP : 0.0) + 2.0 * P.G * spos[I];
     const double vN = ((I < N) ? P.lmda * trN : 0.0) + 2.0 * P.G * (T - spos[I]);
-    sp[I] = vP; sig[I] = g * vP + vN;
+    sig[I] = g * sp[I] + vN;
   }
   const double H = (tr < 0.0) ? 0.0 : 1.0;            // heavisideP(0) == 1 (MathUtils.cpp:33-36)
 #pragma unroll
@@ -338,6 +342,58 @@ __device__ __forceinline__ void miehe_update(const Params& P, const double (&e)[
       const double II = (I < N && J < N) ? 1.0 : 0.0;
       D[I][J] = g * (2.0 * P.G * Pv[I][J] + P.lmda * H * II) + (2.0 * P.G * (I4 - Pv[I][J]) + P.lmda * (1.0 - H) * II);
     }
+}
+
+template <int RANK, int S>
+__device__ __forceinline__ void miehe_update(const Params& P, const double (&e)[S], double g, double (&D)[S][S],
+                                             double (&sig)[S], double (&sp)[S], double& Psi) {
+  miehe_update_f<RANK, S>(P, e, [g](double, const double (&)[S]) { return g; }, D, sig, sp, Psi);
+}
+
+// Local damage of the micromorphic model (MicroPhaseFractureModel.cpp:668-796): Newton iteration on
+// Res(d) = g'(d) Psi + gc/(cw l0) w'(d) + alpha (d - pf), |Res| <= 1e-4 or 100 iterations, then the loading /
+// clipping branches.  Returns g(d) (no floor); out: d, g'(d) at the final d, dphidd and cdS with
+// dphidStrain = cdS * sigma+.  In the `d > 1` branch the reference keeps a dphidStrain left over from an earlier
+// Gauss point of its serial loop; there is no such thing on a GPU, cdS = 0 is used there (documented divergence).
+struct MicroOut { double d, dgphi, dphidd, cdS; };
+__device__ __forceinline__ void micro_terms(const Params& P, double d, double& gn, double& gd, double& dg, double& ddg) {
+  const double x = 1.0 - d;
+  double dgn, ddgn;
+  if (P.ptype == 0)      { gn = x * x;                  dgn = -2.0 * x;           ddgn = 2.0; }
+  else if (P.ptype == 1) { const double sq = sqrt(x);
+                           gn = x * x * sq;             dgn = -2.5 * (x * sq);    ddgn = 2.5 * 1.5 * sq; }
+  else                   { const double x2 = x * x;
+                           gn = x2 * x2;                dgn = -4.0 * (x2 * x);    ddgn = 4.0 * 3.0 * x2; }
+  const double a12 = P.a1 * P.a2, a123 = a12 * P.a3;
+  gd = gn + P.a1 * d + a12 * d * d + a123 * d * d * d;
+  const double dgd  = dgn + P.a1 + 2.0 * a12 * d + 3.0 * a123 * d * d;
+  const double ddgd = ddgn + 2.0 * a12 + 6.0 * a123 * d;
+  const double q = dgn * gd - gn * dgd;
+  dg  = q / (gd * gd);
+  ddg = ((ddgn * gd - gn * ddgd) * gd - 2.0 * q * dgd) / (gd * gd * gd);
+}
+__device__ __forceinline__ double micro_newton(const Params& P, double Psi, double pf, double d0, MicroOut& o) {
+  const double ddw = 2.0 * (1.0 - P.eta);
+  double d = d0, gn, gd, dg, ddg;
+  micro_terms(P, d, gn, gd, dg, ddg);
+  double Res = dg * Psi + P.gcl * (P.eta + 2.0 * (1.0 - P.eta) * d) + P.alpha * (d - pf);
+  double J = ddg * Psi + P.gcl * ddw + P.alpha;
+  for (int iter = 0; fabs(Res) > 1.e-4 && iter < 100; iter++) {
+    d -= Res / J;
+    micro_terms(P, d, gn, gd, dg, ddg);
+    Res = dg * Psi + P.gcl * (P.eta + 2.0 * (1.0 - P.eta) * d) + P.alpha * (d - pf);
+    J = ddg * Psi + P.gcl * ddw + P.alpha;
+  }
+  o.dphidd = 0.0; o.cdS = 0.0;
+  if (d > d0) {
+    const double den = ddg * Psi + P.gcl * ddw + P.alpha;
+    o.cdS = -dg / den; o.dphidd = P.alpha / den;
+  } else if (d < 0.0) d = 0.0;
+  else if (d > 1.0)   d = 1.0;
+  else                d = d0;
+  micro_terms(P, d, gn, gd, dg, ddg);
+  o.d = d; o.dgphi = dg;
+  return gn / gd;
 }
 
 // B_a^T v for a Voigt vector v (2D: xx,yy,xy; 3D: xx,yy,zz,xy,yz,zx), ShapeUtils.cpp:73-145
@@ -368,6 +424,58 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
   if constexpr (!PF) {
     iso_update<RANK, S, SP>(P, eps, 1.0, r.d0, r.d1, r.d3, r.sig, sp, Psi);
   } else {
+    if constexpr (FAM == FAM_PF_MIEHE) {
+      if (SP::model(P) == 4) {                          // MicroPhaseFractureModel.cpp:656-830 (general-tangent family only)
+        MicroOut mo;
+        double gphi = 1.0;
+        auto gfun = [&](double Psi_raw, const double (&)[S]) {
+          const double PsiM = (Psi_raw > P.psi0) ? Psi_raw : P.psi0;
+          gphi = micro_newton(P, PsiM, pf, H0, mo);
+          return gphi;
+        };
+        if (SP::material(P) == 3) {
+          miehe_update_f<RANK, S>(P, eps, gfun, r.D, r.sig, sp, Psi);
+        } else {                                        // BourdinPhase: stiffP = D, stiffN = 0 (BourdinPhaseMaterial.cpp:148-166)
+          double psi2 = 0.0;
+#pragma unroll
+          for (int i = 0; i < S; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < S; j++) {
+              const double dij = (i < RANK && j < RANK) ? ((i == j) ? P.hd0 : P.hd1) : ((i == j) ? P.hd3 : 0.0);
+              acc += dij * eps[j];
+            }
+            sp[i] = acc; psi2 += acc * eps[i];
+          }
+          Psi = 0.5 * psi2;
+          const double g = gfun(Psi, sp);
+#pragma unroll
+          for (int i = 0; i < S; i++) {
+            r.sig[i] = g * sp[i];
+#pragma unroll
+            for (int j = 0; j < S; j++)
+              r.D[i][j] = g * ((i < RANK && j < RANK) ? ((i == j) ? P.hd0 : P.hd1) : ((i == j) ? P.hd3 : 0.0));
+          }
+        }
+        r.d0 = r.d1 = r.d3 = 0.0;
+        const double coef = mo.dgphi * mo.cdS;          // second elemMat1 term: dgphi * sigma+ (x) dphidStrain (:816)
+#pragma unroll
+        for (int i = 0; i < S; i++)
+#pragma unroll
+          for (int j = 0; j < S; j++) r.D[i][j] += coef * (sp[i] * sp[j]);
+        if (P.strain != nullptr && write) P.strain[ipoint * srows + STR] = gphi;
+        if (write) P.hist_new[ipoint] = mo.d;
+        r.c1 = P.alpha * (1.0 - mo.dphidd);             // K4 (:817)
+        r.cf = P.alpha * (pf - mo.d);                   // f2 (:830)
+        r.dg = mo.dgphi * mo.dphidd;                    // K2 (:822)
+        r.dgl = -P.alpha * mo.cdS;                      // K3 (:823)
+        if constexpr (KEEP) {
+#pragma unroll
+          for (int c = 0; c < S; c++) r.sp[c] = sp[c];
+        }
+        return;
+      }
+    }
     double dgphi, ddgphi, loading = 1.0;
     double gmat;
     if (SP::model(P) == 1) {
@@ -400,7 +508,7 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
     const double dw = P.eta + 2.0 * (1.0 - P.eta) * pf, ddw = 2.0 * (1.0 - P.eta);
     r.c1 = P.gcl * ddw + ddgphi * Psi;                  // K4 (:714)
     r.cf = P.gcl * dw + dgphi * Psi;                    // f2 (:728)
-    if ((SP::model(P) >= 2) && (pf0 - pf > 1.e-15)) {        // penalty, PhaseFractureExtModel.cpp:752-758
+    if ((SP::model(P) == 2 || SP::model(P) == 3) && (pf0 - pf > 1.e-15)) {        // penalty, PhaseFractureExtModel.cpp:752-758
       r.c1 += P.gcl * P.beta;
       r.cf -= P.gcl * P.beta * (pf0 - pf);
     }
@@ -513,7 +621,7 @@ __device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, con
 #pragma unroll
       for (int i = 0; i < RANK; i++) r.gphi[i] += r.g[a][i] * E.phi[a];
     }
-    if (SP::model(P) >= 2) {
+    if (SP::model(P) == 2 || SP::model(P) == 3) {
 #pragma unroll
       for (int a = 0; a < NPE; a++) { pf0 += tabN[ip * NPE + a] * E.phi0[a]; pfX += tabN[ip * NPE + a] * E.phiX[a]; }
     }
@@ -649,7 +757,7 @@ __device__ __forceinline__ void compute_rowblock(const Params& P, int64_t e, int
 #pragma unroll
   for (int ip = 0; ip < NIP; ip++) H0v[ip] = 0.0;
   if constexpr (PF) {
-    if (SP::model(P) == 1) {
+    if (SP::model(P) == 1 || SP::model(P) == 4) {
 #pragma unroll
       for (int ip = 0; ip < NIP; ip++) H0v[ip] = P.hist_pre[e * NIP + ip];
     }
@@ -888,7 +996,7 @@ __global__ __launch_bounds__(SH::PBLOCK) void assemble_patch(const Params P) {
   ElemData<SH, PF> E;
   double H0 = 0.0;
   gather_elem<SH, PF>(P, cur.cn, E);
-  if constexpr (PF) { if (P.model == 1) H0 = P.hist_pre[cur.e * SH::NIP + (SH::SHARE ? la : 0)]; }
+  if constexpr (PF) { if (P.model == 1 || P.model == 4) H0 = P.hist_pre[cur.e * SH::NIP + (SH::SHARE ? la : 0)]; }
 
   int cntsum = 0;
 #pragma unroll
@@ -923,7 +1031,7 @@ __global__ __launch_bounds__(SH::PBLOCK) void assemble_patch(const Params P) {
       if (more) {                                            // gathers of the next pass fly during phase 2
         cur = nxt;
         gather_elem<SH, PF>(P, cur.cn, E);
-        if constexpr (PF) { if (P.model == 1) H0 = P.hist_pre[cur.e * SH::NIP + la]; }
+        if constexpr (PF) { if (P.model == 1 || P.model == 4) H0 = P.hist_pre[cur.e * SH::NIP + la]; }
         const int k2 = kb + 2 * GPB + grp;
         if (kb + 2 * GPB < nelem) load_idx<NPE>(P, (int64_t)eb0 + min(k2, nelem - 1), la, k2 < nelem, nxt);
       }
@@ -1159,7 +1267,7 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
 #pragma unroll
     for (int k = 0; k < HALF; k++) H0v[k] = 0.0;
     if constexpr (PF) {
-      if (SP::model(P) == 1) {
+      if (SP::model(P) == 1 || SP::model(P) == 4) {
 #pragma unroll
         for (int k = 0; k < HALF; k++) H0v[k] = P.hist_pre[e * NIP + half * HALF + k];
       }

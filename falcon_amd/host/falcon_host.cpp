@@ -411,6 +411,7 @@ class SolidAssemblyModel : public Model {
       myProps.find(gc_, "griffithEnergy"); myConf.set("griffithEnergy", gc_);
       myProps.find(l0_, "lengthScale"); myConf.set("lengthScale", l0_);
       myProps.find(sigmaT_, "tensileStrength"); myConf.set("tensileStrength", sigmaT_);
+      if (kind_ == FA_MICRO_PHASE_FRACTURE) beta_ = 250.0;               // MicroPhaseFractureModel.cpp:269
       if (kind_ >= FA_PHASE_FRACTURE_EXT) { myProps.find(beta_, "penalty"); myConf.set("penalty", beta_); }
     }
   }
@@ -457,7 +458,7 @@ class SolidAssemblyModel : public Model {
     }
     if (action == Actions::GET_MATRIX2) throw Error(myName_, "GET_MATRIX2 is not served by the GPU assembly path");
     if (action == Actions::COMMIT) {
-      if (kind_ == FA_PHASE_FRACTURE) check_(fa_commit(ctx_));          // newHist_.H0_.swap(preHist_.H0_)
+      if (kind_ == FA_PHASE_FRACTURE || kind_ == FA_MICRO_PHASE_FRACTURE) check_(fa_commit(ctx_));   // newHist_.swap(preHist_)
       if (kind_ == FA_PHASE_FRACTURE_EXT) dt0_ = dt_;                    // PhaseFractureExtModel.cpp:450
       if (kind_ == FA_PHASE_FRACTURE_EXTIT) oIter_ = 0;                  // PhaseFractureExtItModel.cpp:480
       return true;
@@ -465,7 +466,7 @@ class SolidAssemblyModel : public Model {
     if (kind_ == FA_PHASE_FRACTURE_EXTIT) {
       if (action == "checkCommit") { checkCommit_(params, globdat); return true; }   // XActions::CHECK_COMMIT
     } else if (action == Actions::CHECK_COMMIT) return true;
-    if (action == Actions::SET_STEP_SIZE && kind_ >= FA_PHASE_FRACTURE_EXT) {
+    if (action == Actions::SET_STEP_SIZE && (kind_ == FA_PHASE_FRACTURE_EXT || kind_ == FA_PHASE_FRACTURE_EXTIT)) {
       double dt, dt0; params.get(dt, ActionParams::STEP_SIZE); params.get(dt0, ActionParams::STEP_SIZE_0);
       dt_ = dt;
       if (kind_ == FA_PHASE_FRACTURE_EXTIT) dt0_ = dt0;                  // Ext ignores dt0 (PhaseFractureExtModel.cpp:1339)
@@ -516,7 +517,7 @@ class SolidAssemblyModel : public Model {
     Vector state, state0, state00;
     globdat.get(state, Globdat::STATE);                                  // StateVector::get
     const double* s0 = nullptr; const double* s00 = nullptr;
-    if (kind_ >= FA_PHASE_FRACTURE_EXT) {
+    if (kind_ == FA_PHASE_FRACTURE_EXT || kind_ == FA_PHASE_FRACTURE_EXTIT) {
       globdat.get(state0, Globdat::STATE_OLD); globdat.get(state00, Globdat::STATE_OLD_OLD);
       s0 = state0->data(); s00 = state00->data();
       if (kind_ == FA_PHASE_FRACTURE_EXTIT) {                            // PhaseFractureExtItModel.cpp:399-408
@@ -576,6 +577,7 @@ void declareFalconSolidMechModels() {
   ModelFactory::declare("PhaseFracture", &newSolidModel<FA_PHASE_FRACTURE>);
   ModelFactory::declare("PhaseFractureExt", &newSolidModel<FA_PHASE_FRACTURE_EXT>);
   ModelFactory::declare("PhaseFractureExtIt", &newSolidModel<FA_PHASE_FRACTURE_EXTIT>);
+  ModelFactory::declare("MicroPhaseFracture", &newSolidModel<FA_MICRO_PHASE_FRACTURE>);   // first of the micromorphic variants
 }
 
 }  // namespace falcon_host

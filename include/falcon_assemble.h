@@ -31,7 +31,9 @@ enum { FA_TRI3_G1 = 0, FA_TRI3_G3 = 1, FA_QUAD4_G2 = 2, FA_QUAD8_G3 = 3, FA_QUAD
        FA_HEX8_G2 = 6, FA_HEX20_G3 = 7, FA_HEX20_G2 = 8 };
 
 /* ModelFactory names, src/fem/solidmech/FalconSolidMechModels.cpp:10-22 */
-enum { FA_LINEAR_ELASTICITY = 0, FA_PHASE_FRACTURE = 1, FA_PHASE_FRACTURE_EXT = 2, FA_PHASE_FRACTURE_EXTIT = 3 };
+enum { FA_LINEAR_ELASTICITY = 0, FA_PHASE_FRACTURE = 1, FA_PHASE_FRACTURE_EXT = 2, FA_PHASE_FRACTURE_EXTIT = 3,
+       FA_MICRO_PHASE_FRACTURE = 4 /* "MicroPhaseFracture": micromorphic variant, MicroPhaseFractureModel.cpp:502-851;
+                                      history = local damage d (preHist_.phasef_), penalty default 250 */ };
 
 /* material.type, newMaterial, src/materials/Material.cpp:233-244 */
 enum { FA_HOOKE = 0, FA_AMOR_PHASE = 1, FA_BOURDIN_PHASE = 2, FA_MIEHE_PHASE = 3 };

@@ -574,6 +574,68 @@ int fo_material_update(const fo_config* cfg, int rank, const double* strain, dou
 }
 
 /* ------------------------------------------------------------------------- */
+/* Overloaded update(stressP, stressN, stiffP, stiffN, strain) of the micromorphic models */
+/* ------------------------------------------------------------------------- */
+/* AmorPhaseMaterial.cpp:239-268.  NOTE (verbatim): stiffN is assigned only when trace(strain) <= 0; in tension the
+ * caller's array keeps whatever an earlier point left in it (the model's `stiffN` lives outside its element loop,
+ * MicroPhaseFractureModel.cpp:535).  stiffN is therefore in/out here. */
+static void amor_update_split(int rank, double E, double nu, const double* strain,
+                              double* stressP, double* stressN, double* stiffP, double* stiffN, double* psi) {
+  const int n = STRAIN_COUNTS[rank];
+  const double K = E / (3.0 * (1.0 - 2.0 * nu));
+  const double G = E / (2.0 * (1.0 + nu));
+  double PVol[MAXSTR * MAXSTR] = { 0 }, PDev[MAXSTR * MAXSTR] = { 0 };
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    PVol[i * n + j] = 1.0;
+    PDev[i * n + j] = (i == j) ? 2.0 / 3.0 : -1.0 / 3.0;
+  }
+  for (int i = 3; i < n; i++) PDev[i * n + i] = 0.5;
+  double tr = strain[0] + strain[1] + strain[2];
+  for (int i = 0; i < n * n; i++) stiffP[i] = 2.0 * G * PDev[i];
+  if (tr > 0.0) { for (int i = 0; i < n * n; i++) stiffP[i] += K * PVol[i]; }
+  else          { for (int i = 0; i < n * n; i++) stiffN[i] = K * PVol[i]; }
+  matvec(n, stiffP, strain, stressP);
+  matvec(n, stiffN, strain, stressN);
+  *psi = 0.5 * dotn(n, stressP, strain);
+}
+
+/* BourdinPhaseMaterial.cpp:148-166 */
+static int bourdin_update_split(int rank, int state, double E, double nu, const double* strain,
+                                double* stressP, double* stressN, double* stiffP, double* stiffN, double* psi) {
+  const int n = STRAIN_COUNTS[rank];
+  if (hooke_stiff(rank, state, E, nu, stiffP)) return -1;
+  matvec(n, stiffP, strain, stressP);
+  for (int i = 0; i < n; i++) stressN[i] = 0.0;
+  for (int i = 0; i < n * n; i++) stiffN[i] = 0.0;
+  *psi = 0.5 * dotn(n, stressP, strain);
+  return 0;
+}
+
+/* MiehePhaseMaterial.cpp:264-324: jacP = 2G P+ + lambda H I(x)I, jacN = 2G P- + lambda (1-H) I(x)I.  The degraded
+ * update above is g * (P part) + (N part); evaluating it with g = 1 and g = 0 separates the two exactly as written. */
+static void miehe_update_split(int rank, double E, double nu, const double* strain,
+                               double* stressP, double* stressN, double* stiffP, double* stiffN, double* psi) {
+  const int n = STRAIN_COUNTS[rank];
+  double s1[MAXSTR], D1[MAXSTR * MAXSTR], sp[MAXSTR], p1;
+  miehe_update(rank, E, nu, strain, 0.0, stressN, stiffN, psi, sp);       /* g = 0: N part */
+  miehe_update(rank, E, nu, strain, 1.0, s1, D1, &p1, stressP);           /* g = 1: P + N; stressP_ = vP */
+  for (int i = 0; i < n * n; i++) stiffP[i] = D1[i] - stiffN[i];
+}
+
+static int material_update_split(const fo_config* cfg, int rank, const double* strain,
+                                 double* stressP, double* stressN, double* stiffP, double* stiffN, double* psi) {
+  switch (cfg->material) {
+    case FO_AMOR:    amor_update_split(rank, cfg->young, cfg->poisson, strain, stressP, stressN, stiffP, stiffN, psi); return 0;
+    case FO_BOURDIN: return bourdin_update_split(rank, cfg->state, cfg->young, cfg->poisson, strain, stressP, stressN, stiffP, stiffN, psi);
+    case FO_MIEHE:   miehe_update_split(rank, cfg->young, cfg->poisson, strain, stressP, stressN, stiffP, stiffN, psi); return 0;
+  }
+  FAIL("material %d has no positive/negative split", cfg->material);
+}
+
+static __thread int64_t g_micro_stale = 0;
+int64_t fo_micro_stale_hits(void) { return g_micro_stale; }
+
+/* ------------------------------------------------------------------------- */
 /* Fracture constants: PhaseFractureModel.cpp:296-355                        */
 /* ------------------------------------------------------------------------- */
 typedef struct { double cw, eta, p, a1, a2, a3, psi0; } frac_t;
@@ -749,6 +811,11 @@ int fo_assemble(const fo_config* cfg,
   double sPB[MAXND], BeBe[MAXNPE * MAXNPE];
   int64_t dispDofs[MAXND], phiDofs[MAXNPE];
   double errExt = 0.0;
+  /* MicroPhaseFractureModel.cpp:533-538,577: these live outside the element loop, so values left by an earlier
+   * Gauss point stay visible (Amor's stiffN in tension; dphidStrain in the `d > 1` branch).  Jem leaves new arrays
+   * uninitialised; zero is assumed here. */
+  double stiffP[MAXSTR * MAXSTR] = { 0 }, stiffN[MAXSTR * MAXSTR] = { 0 }, stressN[MAXSTR] = { 0 }, dphidStrain[MAXSTR] = { 0 };
+  g_micro_stale = 0;
 
   for (int64_t ie = el_begin; ie < el_end; ie++) {
     const int32_t* inodes = conn + ie * nodeCount;
@@ -762,7 +829,7 @@ int fo_assemble(const fo_config* cfg,
 
     for (int i = 0; i < dispCount; i++) disp[i] = state[dispDofs[i]];
     if (isPF) for (int a = 0; a < phiCount; a++) phi[a] = state[phiDofs[a]];
-    if (model >= FO_PHASE_FRACTURE_EXT)
+    if ((model == FO_PHASE_FRACTURE_EXT || model == FO_PHASE_FRACTURE_EXTIT))
       for (int a = 0; a < phiCount; a++) { phi0[a] = state0[phiDofs[a]]; phiX[a] = state00[phiDofs[a]]; }
 
     memset(elemForce1, 0, sizeof elemForce1); memset(elemForce2, 0, sizeof elemForce2);
@@ -787,6 +854,120 @@ int fo_assemble(const fo_config* cfg,
       if (!isPF) {
         /* LinearElasticityModel.cpp:411-420 */
         if (fo_material_update(cfg, rank, strain, 0.0, stress, stiff, NULL, NULL)) return -1;
+      } else if (model == FO_MICRO_PHASE_FRACTURE) {
+        /* MicroPhaseFractureModel.cpp:656-830 */
+        const double* Nip = sh.N[ip];
+        const double p_ = fr.p, a1_ = fr.a1, a2_ = fr.a2, a3_ = fr.a3;
+        const double alpha = beta_ * gc_ / l0_;
+        double Psi;
+        if (material_update_split(cfg, rank, strain, stressP, stressN, stiffP, stiffN, &Psi)) return -1;
+        Psi = (Psi > Psi0_) ? Psi : Psi0_;
+        const double pf = dotn(phiCount, Nip, phi);
+        const double d0 = hist_pre[ipoint];
+        double d = d0;
+        double gphi_n = pow(1.0 - d, p_);
+        double gphi_d = gphi_n + a1_ * d + a1_ * a2_ * d * d + a1_ * a2_ * a3_ * d * d * d;
+        double dgphi_n = -p_ * (pow(1.0 - d, p_ - 1));
+        double dgphi_d = dgphi_n + a1_ + 2.0 * a1_ * a2_ * d + 3.0 * a1_ * a2_ * a3_ * d * d;
+        double ddgphi_n = p_ * (p_ - 1.0) * (pow(1.0 - d, p_ - 2.0));
+        double ddgphi_d = ddgphi_n + 2.0 * a1_ * a2_ + 6.0 * a1_ * a2_ * a3_ * d;
+        double dgphi = (dgphi_n * gphi_d - gphi_n * dgphi_d) / (gphi_d * gphi_d);
+        double ddgphi = ((ddgphi_n * gphi_d - gphi_n * ddgphi_d) * gphi_d - 2.0 *
+                         (dgphi_n * gphi_d - gphi_n * dgphi_d) * dgphi_d) / (gphi_d * gphi_d * gphi_d);
+        double dw = eta_ + 2.0 * (1.0 - eta_) * d;
+        double ddw = 2.0 * (1.0 - eta_);
+        double Res = dgphi * Psi + gc_ / (cw_ * l0_) * dw + alpha * (d - pf);
+        double J = ddgphi * Psi + gc_ / (cw_ * l0_) * ddw + alpha;
+        int iter = 0;
+        while (fabs(Res) > 1.e-4 && iter < 100) {        /* jem::abs (using namespace jem, MicroPhaseFractureModel.h:58) */
+          iter += 1;
+          d -= Res / J;
+          gphi_n = pow(1.0 - d, p_);
+          gphi_d = gphi_n + a1_ * d + a1_ * a2_ * d * d + a1_ * a2_ * a3_ * d * d * d;
+          dgphi_n = -p_ * (pow(1.0 - d, p_ - 1.0));
+          dgphi_d = dgphi_n + a1_ + 2.0 * a1_ * a2_ * d + 3.0 * a1_ * a2_ * a3_ * d * d;
+          ddgphi_n = p_ * (p_ - 1.0) * (pow(1.0 - d, p_ - 2.0));
+          ddgphi_d = ddgphi_n + 2.0 * a1_ * a2_ + 6.0 * a1_ * a2_ * a3_ * d;
+          dgphi = (dgphi_n * gphi_d - gphi_n * dgphi_d) / (gphi_d * gphi_d);
+          ddgphi = ((ddgphi_n * gphi_d - gphi_n * ddgphi_d) * gphi_d - 2.0 *
+                    (dgphi_n * gphi_d - gphi_n * dgphi_d) * dgphi_d) / (gphi_d * gphi_d * gphi_d);
+          dw = eta_ + 2.0 * (1.0 - eta_) * d;
+          ddw = 2.0 * (1.0 - eta_);
+          Res = dgphi * Psi + gc_ / (cw_ * l0_) * dw + alpha * (d - pf);
+          J = ddgphi * Psi + gc_ / (cw_ * l0_) * ddw + alpha;
+        }
+        double dphidd = 0.0;
+        if (d > d0) {
+          gphi_n = pow(1.0 - d, p_);                      /* gphi_d is NOT recomputed here (commented out, :744) */
+          dgphi_n = -p_ * (pow(1.0 - d, p_ - 1.0));
+          dgphi_d = dgphi_n + a1_ + 2.0 * a1_ * a2_ * d + 3.0 * a1_ * a2_ * a3_ * d * d;
+          ddgphi_n = p_ * (p_ - 1.0) * (pow(1.0 - d, p_ - 2.0));
+          ddgphi_d = ddgphi_n + 2.0 * a1_ * a2_ + 6.0 * a1_ * a2_ * a3_ * d;
+          dgphi = (dgphi_n * gphi_d - gphi_n * dgphi_d) / (gphi_d * gphi_d);
+          ddgphi = ((ddgphi_n * gphi_d - gphi_n * ddgphi_d) * gphi_d - 2.0 *
+                    (dgphi_n * gphi_d - gphi_n * dgphi_d) * dgphi_d) / (gphi_d * gphi_d * gphi_d);
+          ddw = 2.0 * (1.0 - eta_);
+          const double den = ddgphi * Psi + gc_ / (cw_ * l0_) * ddw + alpha;
+          for (int c = 0; c < strCount; c++) dphidStrain[c] = -(dgphi) / den * stressP[c];
+          dphidd = alpha / den;
+        } else if (d < 0.0) {
+          d = 0.0;
+          for (int c = 0; c < strCount; c++) dphidStrain[c] = 0.0;
+          dphidd = 0.0;
+        } else if (d > 1.0) {
+          d = 1.0;                                        /* dphidStrain keeps its previous contents (:772-776) */
+          dphidd = 0.0;
+          g_micro_stale++;
+        } else {
+          d = d0;
+          for (int c = 0; c < strCount; c++) dphidStrain[c] = 0.0;
+          dphidd = 0.0;
+        }
+        gphi_n = pow(1.0 - d, p_);
+        gphi_d = gphi_n + a1_ * d + a1_ * a2_ * d * d + a1_ * a2_ * a3_ * d * d * d;
+        dgphi_n = -p_ * (pow(1.0 - d, p_ - 1.0));
+        dgphi_d = dgphi_n + a1_ + 2.0 * a1_ * a2_ * d + 3.0 * a1_ * a2_ * a3_ * d * d;
+        const double gphi = gphi_n / gphi_d;             /* no floor here (:795) */
+        dgphi = (dgphi_n * gphi_d - gphi_n * dgphi_d) / (gphi_d * gphi_d);
+        if (strain_cache) strain_cache[ipoint * srows + strCount] = gphi;
+        hist_new[ipoint] = d;
+        /* stiff = gphi*stiffP + stiffN (:804) plus the second elemMat1 term w*dgphi*bdt*(stressP (x) dphidStrain)*bd (:816),
+         * folded into one matrix for the common B^T D B product below */
+        for (int c = 0; c < strCount; c++) {
+          stress[c] = gphi * stressP[c] + stressN[c];
+          for (int k = 0; k < strCount; k++)
+            stiff[c * strCount + k] = gphi * stiffP[c * strCount + k] + stiffN[c * strCount + k]
+                                      + dgphi * (stressP[c] * dphidStrain[k]);
+        }
+        for (int a = 0; a < phiCount; a++) for (int b = 0; b < phiCount; b++) {
+          double s = 0.0;
+          for (int i = 0; i < rank; i++) s += grads[ip][a][i] * grads[ip][b][i];
+          BeBe[a * phiCount + b] = s;
+        }
+        const double c2 = 2.0 * gc_ * l0_ / cw_;
+        if (mbuilder) {
+          for (int a = 0; a < phiCount; a++) for (int b = 0; b < phiCount; b++)
+            elemMat4[a * phiCount + b] += wip * (alpha * (1.0 - dphidd) * (Nip[a] * Nip[b]) + c2 * BeBe[a * phiCount + b]);
+          if (cfg->keep_off_diags) {
+            for (int j = 0; j < dispCount; j++) {          /* matmul(dphidStrain, bd) */
+              double s = 0.0;
+              for (int c = 0; c < strCount; c++) s += dphidStrain[c] * bd[c * dispCount + j];
+              sPB[j] = s;
+            }
+            for (int i = 0; i < dispCount; i++) for (int b = 0; b < phiCount; b++) {
+              double s = 0.0;
+              for (int c = 0; c < strCount; c++) s += bd[c * dispCount + i] * (stressP[c] * Nip[b]);
+              elemMat2[i * phiCount + b] += wip * dgphi * dphidd * s;
+            }
+            for (int a = 0; a < phiCount; a++) for (int j = 0; j < dispCount; j++)
+              elemMat3[a * dispCount + j] -= wip * alpha * (Nip[a] * sPB[j]);
+          }
+        }
+        for (int a = 0; a < phiCount; a++) {
+          double s = 0.0;
+          for (int b = 0; b < phiCount; b++) s += BeBe[a * phiCount + b] * phi[b];
+          elemForce2[a] += wip * (alpha * (pf - d) * Nip[a] + c2 * s);
+        }
       } else {
         const double* Nip = sh.N[ip];
         double pf = dotn(phiCount, Nip, phi);
@@ -863,7 +1044,7 @@ int fo_assemble(const fo_config* cfg,
             elemForce2[a] += wip * (Nip[a] * cf + c2 * s);
           }
         }
-        if (model >= FO_PHASE_FRACTURE_EXT && (pf0 - pf > 1.e-15)) {   /* PhaseFractureExtModel.cpp:752-758 */
+        if ((model == FO_PHASE_FRACTURE_EXT || model == FO_PHASE_FRACTURE_EXTIT) && (pf0 - pf > 1.e-15)) {   /* PhaseFractureExtModel.cpp:752-758 */
           const double cp = gc_ / (cw_ * l0_) * beta_;
           if (mbuilder) for (int a = 0; a < phiCount; a++) for (int b = 0; b < phiCount; b++)
             elemMat4[a * phiCount + b] += wip * (cp * (Nip[a] * Nip[b]));
@@ -894,8 +1075,9 @@ int fo_assemble(const fo_config* cfg,
     if (mbuilder) {
       if (add_block(row_ptr, col_idx, Kval, dispCount, dispDofs, dispCount, dispDofs, elemMat1)) return -1;
       if (isPF) {
-        const int k2 = (model == FO_PHASE_FRACTURE) && cfg->keep_off_diags;
-        const int k3 = (model == FO_PHASE_FRACTURE) ? cfg->keep_off_diags : 1;
+        const int plain = (model == FO_PHASE_FRACTURE) || (model == FO_MICRO_PHASE_FRACTURE);
+        const int k2 = plain && cfg->keep_off_diags;
+        const int k3 = plain ? cfg->keep_off_diags : 1;
         if (add_block(row_ptr, col_idx, Kval, phiCount, phiDofs, phiCount, phiDofs, elemMat4)) return -1;
         if (k2 && add_block(row_ptr, col_idx, Kval, dispCount, dispDofs, phiCount, phiDofs, elemMat2)) return -1;
         if (k3 && add_block(row_ptr, col_idx, Kval, phiCount, phiDofs, dispCount, dispDofs, elemMat3)) return -1;

@@ -42,7 +42,8 @@ enum {
   FO_LINEAR_ELASTICITY   = 0,
   FO_PHASE_FRACTURE      = 1,
   FO_PHASE_FRACTURE_EXT  = 2,
-  FO_PHASE_FRACTURE_EXTIT= 3
+  FO_PHASE_FRACTURE_EXTIT= 3,
+  FO_MICRO_PHASE_FRACTURE= 4   /* MicroPhaseFractureModel.cpp:502-851 (micromorphic: local damage d by Newton) */
 };
 
 /* material ids: newMaterial, src/materials/Material.cpp:233-244 */
@@ -80,6 +81,9 @@ int  fo_shape_tables(int shape, double* N, double* dN, double* w);
 
 /* dofs per node for a model */
 int  fo_ndof_per_node(int model, int rank);
+/* number of Gauss points of the last fo_assemble call (this thread) that took the `d > 1` branch of
+ * MicroPhaseFractureModel.cpp:772-776, where the reference uses a dphidStrain left over from an earlier point */
+int64_t fo_micro_stale_hits(void);
 
 /* Psi0 = initial history value, PhaseFractureModel.cpp:296-359 */
 double fo_psi0(const fo_config* cfg);

@@ -16,7 +16,7 @@ _LIB = os.path.join(_HERE, "libfalcon_oracle.so")
 # shape ids
 TRI3_G1, TRI3_G3, QUAD4_G2, QUAD8_G3, QUAD8_G2, TRI6_G3, HEX8_G2, HEX20_G3, HEX20_G2 = range(9)
 # models
-LINEAR_ELASTICITY, PHASE_FRACTURE, PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT = range(4)
+LINEAR_ELASTICITY, PHASE_FRACTURE, PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT, MICRO_PHASE_FRACTURE = range(5)
 # materials
 HOOKE, AMOR, BOURDIN, MIEHE = range(4)
 PLANE_STRAIN, PLANE_STRESS = 0, 1
@@ -53,6 +53,7 @@ def lib():
         L.fo_shape_info_get.argtypes = [C.c_int, C.POINTER(ShapeInfo)]
         L.fo_shape_tables.argtypes = [C.c_int, dp, dp, dp]
         L.fo_ndof_per_node.argtypes = [C.c_int, C.c_int]
+        L.fo_micro_stale_hits.restype = C.c_int64
         L.fo_psi0.argtypes = [C.POINTER(Config)]
         L.fo_psi0.restype = C.c_double
         L.fo_degradation.argtypes = [C.POINTER(Config), C.c_double, dp, dp, dp]
@@ -117,7 +118,7 @@ def material_update(cfg, rank, strain, gphi=1.0):
 
 def keep_code(cfg):
     """keep_off_diags code of fo_pattern for the WRITTEN pattern of this model."""
-    if cfg.model == PHASE_FRACTURE:
+    if cfg.model in (PHASE_FRACTURE, MICRO_PHASE_FRACTURE):
         return 1 if cfg.keep_off_diags else 0
     if cfg.model in (PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT):
         return 2
@@ -155,9 +156,9 @@ def assemble(cfg, coords, conn, row_ptr, col_idx, state, state0=None, state00=No
         K = np.zeros(row_ptr[-1])
     if f is None:
         f = np.zeros(ndof)
-    if cfg.model == PHASE_FRACTURE:
-        if hist_pre is None:
-            hist_pre = np.full(nel * nip, psi0(cfg))
+    if cfg.model in (PHASE_FRACTURE, MICRO_PHASE_FRACTURE):
+        if hist_pre is None:     # preHist_.H0_ = Psi0_ (PhaseFractureModel.cpp:359); preHist_.phasef_ = 0 (MicroPhaseFractureModel.cpp:359)
+            hist_pre = np.full(nel * nip, psi0(cfg) if cfg.model == PHASE_FRACTURE else 0.0)
         hist_pre = np.ascontiguousarray(hist_pre, dtype=np.float64)
         if hist_new is None:
             hist_new = np.zeros(nel * nip)
@@ -179,4 +180,5 @@ def assemble(cfg, coords, conn, row_ptr, col_idx, state, state0=None, state00=No
                            C.byref(err))
     if rc:
         raise ValueError(lib().fo_last_error().decode())
-    return dict(K=K if want_K else None, f=f, hist_new=hist_new, strain=strain, err_ext=err.value)
+    return dict(K=K if want_K else None, f=f, hist_new=hist_new, strain=strain, err_ext=err.value,
+                micro_stale_hits=int(lib().fo_micro_stale_hits()))

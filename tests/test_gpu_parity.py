@@ -63,7 +63,7 @@ def run_both(shape, model, material, *, keep=0, kind=capi.PATTERN_FULL, flags=ca
     err = torch.zeros(1, dtype=torch.float64, device=dev)
     if model == capi.PHASE_FRACTURE:
         asm.set_history(0, H0)
-    ext = model >= capi.PHASE_FRACTURE_EXT
+    ext = model in (capi.PHASE_FRACTURE_EXT, capi.PHASE_FRACTURE_EXTIT)
     asm.assemble(d(st), K, f, state0=d(st0) if ext else None, state00=d(st00) if ext else None, dt=0.7, dt0=0.4,
                  err_ext=err, flags=flags | capi.STORE_STRAIN)
     torch.cuda.synchronize()
@@ -377,3 +377,65 @@ def test_full_size_invariants_cfg3():
     asm.assemble(st, K2, f3, flags=capi.ACCUMULATE)
     torch.cuda.synchronize()
     assert (K - K2).abs().max().item() < 1e-12 * kmax and (f - f3).abs().max().item() < 1e-12 * fmax
+
+
+# ---- micromorphic variant MicroPhaseFracture ----
+ALL_SHAPES = [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2] + HIGH_ORDER
+
+
+def run_micro(shape, material, keep, *, flags=capi.OVERWRITE, want_K=True, commit=False, frac=capi.AT2, sigma_t=0.0,
+              young=210.0, gc=2.7e-3, l0=0.2, tol=TOL):
+    import torch
+    coords, conn, st, kw, cfg = make_case(shape, capi.MICRO_PHASE_FRACTURE, material, keep, frac=frac, sigma_t=sigma_t,
+                                          young=young, gc=gc, l0=l0)
+    kw["beta"] = 250.0
+    cfg = po.make_config(shape, po.MICRO_PHASE_FRACTURE, material, **kw)
+    asm = capi.Assembler(shape, capi.MICRO_PHASE_FRACTURE, material, coords, conn, **kw)
+    rp, ci = asm.pattern()
+    rpo, cio = po.pattern(coords.shape[0], conn, asm.ndofpn, coords.shape[1], po.PATTERN_FULL, po.keep_code(cfg))
+    assert np.array_equal(rp, rpo) and np.array_equal(ci, cio)
+    rng = np.random.default_rng(5)
+    d0 = rng.uniform(0.0, 0.4, conn.shape[0] * asm.nip)           # committed local damage: some points load, some do not
+    asm.set_history(0, d0)
+    dev = torch.device("cuda", 0)
+    K = torch.full((asm.nnz,), 3.0, dtype=torch.float64, device=dev) if want_K else None
+    f = torch.full((asm.ndof,), -2.0, dtype=torch.float64, device=dev)
+    asm.assemble(torch.from_numpy(st).to(dev), K, f, flags=flags | capi.STORE_STRAIN)
+    torch.cuda.synchronize()
+    ref = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=d0, want_K=want_K, want_strain=True)
+    assert ref["micro_stale_hits"] == 0
+    loading = (ref["hist_new"] > d0).mean()
+    assert 0.05 < loading < 0.95                                  # both branches of :738-782 are exercised
+    if want_K:
+        assert rel_rowmax_err(rp, K.cpu().numpy(), ref["K"]) < tol
+    assert vec_err(f.cpu().numpy(), ref["f"]) < tol
+    assert np.abs(asm.get_history(1) - ref["hist_new"]).max() < tol
+    assert np.abs(asm.get_strain_cache() - ref["strain"]).max() < tol * np.abs(ref["strain"]).max()
+    if commit:                                                    # COMMIT: newHist_.phasef_.swap(preHist_.phasef_) (:458-463)
+        asm.commit()
+        assert np.abs(asm.get_history(0) - ref["hist_new"]).max() < tol
+    return asm
+
+
+@pytest.mark.parametrize("shape", ALL_SHAPES)
+@pytest.mark.parametrize("material", [capi.BOURDIN_PHASE, capi.MIEHE_PHASE])
+def test_micro_phase_fracture(shape, material):
+    run_micro(shape, material, keep=0)
+    run_micro(shape, material, keep=1, commit=True)
+    run_micro(shape, material, keep=0, want_K=False)
+
+
+@pytest.mark.parametrize("frac", [capi.AT1, capi.CZM_EXPONENTIAL, capi.CZM_HYPERBOLIC])
+def test_micro_fracture_laws(frac):
+    """The local Newton iteration runs through (1-d)^p with p = 2.5 / 4 (pow on the host, sqrt / squares on the device)
+    and several quotient-rule cancellations per step: the rounding differences it amplifies reach a few 1e-12, so
+    the bar is 1e-11 here (1e-12 everywhere else)."""
+    run_micro(capi.QUAD4_G2, capi.MIEHE_PHASE, keep=1, frac=frac, sigma_t=3.0, young=3e4, gc=0.12, l0=0.25, tol=1e-11)
+
+
+def test_micro_amor_is_refused():
+    """AmorPhase's split update reads a stiffN left by an earlier Gauss point of the reference's serial loop; the
+    library refuses the combination instead of returning something order-dependent."""
+    coords, conn = meshgen.grid_quad4(3, 3)
+    with pytest.raises(capi.FaError, match="serial Gauss-point order"):
+        capi.Assembler(capi.QUAD4_G2, capi.MICRO_PHASE_FRACTURE, capi.AMOR_PHASE, coords, conn)

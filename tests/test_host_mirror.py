@@ -117,3 +117,35 @@ def test_phase_fracture_models_through_take_action():
     ok, K, f = case.take_action("GET_MATRIX0", state=st, state0=st0, state00=st00, iter_count=0)
     r = po.assemble(cfg, coords, conn, rp, ci, st, state0=st0, state00=0.25 * ext + 0.75 * st)
     assert ok and np.abs(f - r["f"]).max() < 1e-12 * np.abs(f).max()
+
+
+@pytest.mark.gpu
+def test_micro_phase_fracture_through_take_action():
+    """"MicroPhaseFracture" (first of the micromorphic variants): GET_MATRIX0, COMMIT (local damage swap),
+    GET_INT_VECTOR; penalty defaults to 250 (MicroPhaseFractureModel.cpp:269)."""
+    from falcon_amd import meshgen
+    from oracle import pyoracle as po
+    coords, conn = meshgen.grid_quad4(6, 5)
+    coords = meshgen.distort(coords, conn, 0.1)
+    mesh = "<Nodes>\n" + "".join(f"{i + 1} {x:.17g} {y:.17g};\n" for i, (x, y) in enumerate(coords)) + "</Nodes>\n"
+    mesh += "<Elements>\n" + "".join(f"{e + 1} " + " ".join(str(n + 1) for n in c) + ";\n" for e, c in enumerate(conn))
+    mesh += "</Elements>\n<ElementGroup name=\"all\">\n{" + ",".join(str(e + 1) for e in range(len(conn))) + "}\n</ElementGroup>\n"
+    pro = '''model = "Matrix" { matrix.type = "FEM"; model = "Multi" { models = ["bulk"];
+      bulk = "MicroPhaseFracture" { elements = "all"; shape = { type = "Quad4"; intScheme = "Gauss2*Gauss2"; };
+        material = { type = "MiehePhase"; rank = 2; state = "PLANE_STRAIN"; young = 210.0; poisson = 0.3; };
+        fractureType = "at2"; griffithEnergy = 2.7e-3; lengthScale = 0.2; keepOffDiags = true; }; }; };'''
+    st = meshgen.smooth_state(coords, 3, amp=5e-3, noise=1e-4, l0=0.3)
+    case = hostapi.Case(pro, mesh)
+    assert case.model_type == "MicroPhaseFracture"
+    rp, ci = case.pattern()
+    cfg = po.make_config(po.QUAD4_G2, po.MICRO_PHASE_FRACTURE, po.MIEHE, young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2,
+                         keep_off_diags=1, beta=250.0)
+    ok, K, f = case.take_action("GET_MATRIX0", state=st)
+    r1 = po.assemble(cfg, coords, conn, rp, ci, st)
+    assert ok and np.abs(K - r1["K"]).max() < 1e-12 * np.abs(K).max() and np.abs(f - r1["f"]).max() < 1e-12 * np.abs(f).max()
+    assert case.take_action("COMMIT")[0]
+    st2 = st * 0.5                                          # unloading: d stays at the committed value
+    ok, _, f2 = case.take_action("GET_INT_VECTOR", state=st2)
+    r2 = po.assemble(cfg, coords, conn, rp, ci, st2, hist_pre=r1["hist_new"], want_K=False)
+    assert ok and np.abs(f2 - r2["f"]).max() < 1e-12 * np.abs(f2).max()
+    assert case.take_action("setStepSize", step=0.5, step0=0.1)[0] is False

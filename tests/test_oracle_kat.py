@@ -299,3 +299,50 @@ def test_pattern_kinds():
     assert rpe[-1] == 7 * pairs
     for r in range(len(rp) - 1):
         assert np.all(np.diff(ci[rp[r]:rp[r + 1]]) > 0)
+
+
+# ---- micromorphic variant (MicroPhaseFractureModel.cpp:502-851) ----
+@pytest.mark.parametrize("material", [po.BOURDIN, po.MIEHE, po.AMOR])
+def test_micro_consistent_tangent(material):
+    """With keepOffDiags the four blocks are the exact derivative of (f1, f2) w.r.t. (u, phi): the rank-one term of
+    elemMat1, dphidd in K4 and the two off-diagonal blocks all come from the implicit function d(eps, pf).  (The local
+    Newton stops at |Res| <= 1e-4, so the check is made with a tight penalty where it converges in a few steps.)"""
+    coords, conn = meshgen.grid_quad4(5, 4)
+    coords = meshgen.distort(coords, conn, 0.1)
+    st = meshgen.smooth_state(coords, 3, amp=5e-3, noise=1e-4, l0=0.3)
+    cfg = po.make_config(po.QUAD4_G2, po.MICRO_PHASE_FRACTURE, material, young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2,
+                         beta=250.0, keep_off_diags=1)
+    rp, ci = po.pattern(coords.shape[0], conn, 3, 2, po.PATTERN_FULL, po.keep_code(cfg))
+    r = po.assemble(cfg, coords, conn, rp, ci, st)
+    assert r["micro_stale_hits"] == 0 and 0.0 < r["hist_new"].max() < 1.0
+    n = st.size
+    Kd = np.zeros((n, n))
+    for i in range(n):
+        Kd[i, ci[rp[i]:rp[i + 1]]] = r["K"][rp[i]:rp[i + 1]]
+    v = np.random.default_rng(0).standard_normal(n); h = 1e-6
+    fp = po.assemble(cfg, coords, conn, rp, ci, st + h * v, want_K=False)["f"]
+    fm = po.assemble(cfg, coords, conn, rp, ci, st - h * v, want_K=False)["f"]
+    fd = (fp - fm) / (2 * h)
+    assert np.abs(Kd @ v - fd).max() < 2e-6 * np.abs(fd).max()
+
+
+def test_micro_unloading_and_limits():
+    """d never decreases below the committed value (else-branch d = d0, :777-782); with zero strain and phi = 0 nothing
+    drives damage (AT2: Res(0) = 0) so d stays 0, g = 1 and K4 = alpha N N^T + c2 B^T B, f = 0."""
+    coords, conn = meshgen.grid_quad4(3, 3)
+    cfg = po.make_config(po.QUAD4_G2, po.MICRO_PHASE_FRACTURE, po.BOURDIN, young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2,
+                         beta=250.0, keep_off_diags=0)
+    rp, ci = po.pattern(coords.shape[0], conn, 3, 2, po.PATTERN_FULL, 0)
+    st = np.zeros(coords.shape[0] * 3)
+    r = po.assemble(cfg, coords, conn, rp, ci, st, want_strain=True)
+    assert np.all(r["hist_new"] == 0.0) and np.abs(r["f"]).max() == 0.0
+    assert np.all(r["strain"][:, 4] == 1.0)                      # g(0) = 1, no floor (:795)
+    alpha = 250.0 * 2.7e-3 / 0.2
+    n = st.size
+    phi_rows = np.arange(2, n, 3)
+    rowsum = np.array([r["K"][rp[i]:rp[i + 1]][ci[rp[i]:rp[i + 1]] % 3 == 2].sum() for i in phi_rows])
+    # sum_b K4[a,b] = alpha * int N_a (the gradient part sums to zero); the nodal integrals add up to the area
+    assert abs(rowsum.sum() - alpha * 1.0) < 1e-12 * alpha
+    hist = np.full(conn.shape[0] * 4, 0.3)
+    r2 = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=hist)
+    assert np.all(r2["hist_new"] == 0.3)
