@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get("FA_LIB") or os.path.join(_HERE, "libfalcon_assemble.s
 
 # enums of include/falcon_assemble.h
 TRI3_G1, TRI3_G3, QUAD4_G2, QUAD8_G3, QUAD8_G2, TRI6_G3, HEX8_G2, HEX20_G3, HEX20_G2 = range(9)
-LINEAR_ELASTICITY, PHASE_FRACTURE, PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT, MICRO_PHASE_FRACTURE = range(5)
+(LINEAR_ELASTICITY, PHASE_FRACTURE, PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT, MICRO_PHASE_FRACTURE,
+ MICRO_PHASE_FRACTURE_EXT, MICRO_PHASE_FRACTURE_EXTIT) = range(7)
 HOOKE, AMOR_PHASE, BOURDIN_PHASE, MIEHE_PHASE = range(4)
 PLANE_STRAIN, PLANE_STRESS = 0, 1
 AT1, AT2, CZM_LINEAR, CZM_EXPONENTIAL, CZM_CORNELISSEN, CZM_HYPERBOLIC = range(6)

@@ -292,7 +292,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     return fail(FA_ERR_ARG, "unknown shape id %d", p->shape);
   c->launch = launcher_for(p->shape);
   c->rank = sh.rank; c->npe = sh.npe; c->nip = sh.nip; c->str = (sh.rank == 2) ? 4 : 6;
-  if (p->model < FA_LINEAR_ELASTICITY || p->model > FA_MICRO_PHASE_FRACTURE) return fail(FA_ERR_ARG, "invalid model %d", p->model);
+  if (p->model < FA_LINEAR_ELASTICITY || p->model > FA_MICRO_PHASE_FRACTURE_EXTIT) return fail(FA_ERR_ARG, "invalid model %d", p->model);
   const bool pf = p->model != FA_LINEAR_ELASTICITY;
   c->ndofpn = pf ? sh.rank + 1 : sh.rank;
   c->srows = pf ? c->str + 1 : c->str;
@@ -301,10 +301,10 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   if (pf && p->material == FA_HOOKE) return fail(FA_ERR_ARG, "phase-field models need a PhaseFractureMaterial");
   if (p->material < FA_HOOKE || p->material > FA_MIEHE_PHASE) return fail(FA_ERR_ARG, "Invalid material: %d", p->material);
   c->fam = !pf ? fa::FAM_LE : (p->material == FA_MIEHE_PHASE ? fa::FAM_PF_MIEHE : fa::FAM_PF_ISO);
-  if (p->model == FA_MICRO_PHASE_FRACTURE) {
+  if (p->model >= FA_MICRO_PHASE_FRACTURE) {
     // AmorPhase's split update leaves stiffN untouched in tension (AmorPhaseMaterial.cpp:239-268), so the reference's
     // result depends on what an earlier Gauss point of its serial loop left there: not reproducible in parallel
-    if (p->material == FA_AMOR_PHASE) return fail(FA_ERR_UNSUPPORTED, "MicroPhaseFracture with AmorPhase depends on the serial Gauss-point order of the reference (stale stiffN); not available on the device");
+    if (p->material == FA_AMOR_PHASE) return fail(FA_ERR_UNSUPPORTED, "MicroPhaseFracture* with AmorPhase depends on the serial Gauss-point order of the reference (stale stiffN); not available on the device");
     c->fam = fa::FAM_PF_MIEHE;                          // general-tangent family (rank-one term of elemMat1)
   }
   if (sh.rank == 2 && p->state != FA_PLANE_STRAIN && p->state != FA_PLANE_STRESS)
@@ -683,13 +683,13 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     if ((st = upload(&c->d_tab, tab.data(), tab.size()))) return st;
   }
   const int64_t nipt = nel * sh.nip;
-  if (p->model == FA_PHASE_FRACTURE || p->model == FA_MICRO_PHASE_FRACTURE) {
+  if (p->model == FA_PHASE_FRACTURE || p->model >= FA_MICRO_PHASE_FRACTURE) {
     for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void**)&c->d_hist[k], std::max<int64_t>(nipt, 1) * sizeof(double)));
     // preHist_.H0_ = Psi0_; newHist_.H0_ = 0 (PhaseFractureModel.cpp:359-360)
     hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[0], nipt, p->model == FA_PHASE_FRACTURE ? P.psi0 : 0.0);   // preHist_.phasef_ = 0 (MicroPhaseFractureModel.cpp:359)
     hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[1], nipt, 0.0);
   }
-  if (p->model == FA_PHASE_FRACTURE_EXTIT)
+  if (p->model == FA_PHASE_FRACTURE_EXTIT || p->model == FA_MICRO_PHASE_FRACTURE_EXTIT)
     HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(std::max(std::max(std::max(c->nwg, c->ntile2), c->ngrid_generic), c->npatch), c->ngrid_coop)));
   HIP_TRY(hipDeviceSynchronize());
 
@@ -757,6 +757,8 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   const int model = c->prob.model;
   if ((model == FA_PHASE_FRACTURE_EXT || model == FA_PHASE_FRACTURE_EXTIT) && (!a->state0 || !a->state00))
     return fail(FA_ERR_ARG, "PhaseFractureExt/ExtIt need state0 and state00 (stateExt_)");
+  if ((model == FA_MICRO_PHASE_FRACTURE_EXT || model == FA_MICRO_PHASE_FRACTURE_EXTIT) && !a->state00)
+    return fail(FA_ERR_ARG, "MicroPhaseFractureExt/ExtIt need state00 (stateExt_)");
   // LinearElasticityModel answers GET_MATRIX0 only (LinearElasticityModel.cpp:226-246); force-only is still
   // served here because the kernel supports it.
   HIP_TRY(hipSetDevice(c->prob.device));
@@ -771,7 +773,7 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
     if (!c->d_strain) HIP_TRY(hipMalloc((void**)&c->d_strain, sizeof(double) * std::max<int64_t>(1, c->nel * c->nip * c->srows)));
     P.strain = c->d_strain;
   }
-  const bool want_err = (model == FA_PHASE_FRACTURE_EXTIT) && a->err_ext;
+  const bool want_err = (model == FA_PHASE_FRACTURE_EXTIT || model == FA_MICRO_PHASE_FRACTURE_EXTIT) && a->err_ext;
   P.err_part = want_err ? c->d_err_part : nullptr;
   const bool want_K = a->K_values != nullptr;
   const bool keep = want_K && (P.keep2 || P.keep3);
@@ -858,7 +860,7 @@ extern "C" fa_status fa_assemble_host(fa_ctx* c, const double* state, const doub
   if (K && (st = fetch(K, c->s_K, (size_t)c->nnz))) return st;
   if ((st = fetch(f, c->s_f, (size_t)c->ndof))) return st;
   if (err_ext) {
-    if (c->prob.model == FA_PHASE_FRACTURE_EXTIT) HIP_TRY(hipMemcpy(err_ext, c->s_err, sizeof(double), hipMemcpyDeviceToHost));
+    if (c->prob.model == FA_PHASE_FRACTURE_EXTIT || c->prob.model == FA_MICRO_PHASE_FRACTURE_EXTIT) HIP_TRY(hipMemcpy(err_ext, c->s_err, sizeof(double), hipMemcpyDeviceToHost));
     else *err_ext = 0.0;
   }
   return FA_OK;
@@ -866,7 +868,7 @@ extern "C" fa_status fa_assemble_host(fa_ctx* c, const double* state, const doub
 
 extern "C" fa_status fa_commit(fa_ctx* c) {
   if (!c) return fail(FA_ERR_ARG, "null argument");
-  if (c->prob.model == FA_PHASE_FRACTURE || c->prob.model == FA_MICRO_PHASE_FRACTURE) std::swap(c->d_hist[0], c->d_hist[1]);
+  if (c->prob.model == FA_PHASE_FRACTURE || c->prob.model >= FA_MICRO_PHASE_FRACTURE) std::swap(c->d_hist[0], c->d_hist[1]);
   return FA_OK;
 }
 

@@ -139,6 +139,7 @@ __device__ __forceinline__ void gather_elem(const Params& P, const int32_t (&cn)
     if constexpr (PF) {
       E.phi[a] = P.state[dofs[RANK]];
       if (SP::model(P) == 2 || SP::model(P) == 3) { E.phi0[a] = P.state0[dofs[RANK]]; E.phiX[a] = P.stateX[dofs[RANK]]; }
+      else if (SP::model(P) >= 5) { E.phi0[a] = 0.0; E.phiX[a] = P.stateX[dofs[RANK]]; }   // stateExt_ only
       else { E.phi0[a] = 0.0; E.phiX[a] = 0.0; }
     }
   }
@@ -372,18 +373,29 @@ __device__ __forceinline__ void micro_terms(const Params& P, double d, double& g
   dg  = q / (gd * gd);
   ddg = ((ddgn * gd - gn * ddgd) * gd - 2.0 * q * dgd) / (gd * gd * gd);
 }
-__device__ __forceinline__ double micro_newton(const Params& P, double Psi, double pf, double d0, MicroOut& o) {
+// Newton iteration proper: starts at d, returns the last iterate with g'(d), g''(d) at it.
+__device__ __forceinline__ double micro_iterate(const Params& P, double Psi, double target, double d, double& dg,
+                                                double& ddg) {
   const double ddw = 2.0 * (1.0 - P.eta);
-  double d = d0, gn, gd, dg, ddg;
+  double gn, gd;
   micro_terms(P, d, gn, gd, dg, ddg);
-  double Res = dg * Psi + P.gcl * (P.eta + 2.0 * (1.0 - P.eta) * d) + P.alpha * (d - pf);
+  double Res = dg * Psi + P.gcl * (P.eta + 2.0 * (1.0 - P.eta) * d) + P.alpha * (d - target);
   double J = ddg * Psi + P.gcl * ddw + P.alpha;
   for (int iter = 0; fabs(Res) > 1.e-4 && iter < 100; iter++) {
     d -= Res / J;
     micro_terms(P, d, gn, gd, dg, ddg);
-    Res = dg * Psi + P.gcl * (P.eta + 2.0 * (1.0 - P.eta) * d) + P.alpha * (d - pf);
+    Res = dg * Psi + P.gcl * (P.eta + 2.0 * (1.0 - P.eta) * d) + P.alpha * (d - target);
     J = ddg * Psi + P.gcl * ddw + P.alpha;
   }
+  return d;
+}
+// dstart: where the iteration starts (d0 for MicroPhaseFracture; the first solve's damage for the Ext variants,
+// MicroPhaseFractureExtModel.cpp:795-850); the branches always compare with the committed d0.
+__device__ __forceinline__ double micro_newton(const Params& P, double Psi, double pf, double dstart, double d0,
+                                               MicroOut& o) {
+  const double ddw = 2.0 * (1.0 - P.eta);
+  double gn, gd, dg, ddg;
+  double d = micro_iterate(P, Psi, pf, dstart, dg, ddg);
   o.dphidd = 0.0; o.cdS = 0.0;
   if (d > d0) {
     const double den = ddg * Psi + P.gcl * ddw + P.alpha;
@@ -394,6 +406,17 @@ __device__ __forceinline__ double micro_newton(const Params& P, double Psi, doub
   micro_terms(P, d, gn, gd, dg, ddg);
   o.d = d; o.dgphi = dg;
   return gn / gd;
+}
+// First solve of the Ext variants (MicroPhaseFractureExtModel.cpp:728-790): damage for the extrapolated micromorphic
+// variable, clipped to [0,1] and made irreversible; returns g(d) + 1e-10.
+__device__ __forceinline__ double micro_first_solve(const Params& P, double Psi, double pfEx, double d0, double& dout) {
+  double gn, gd, dg, ddg;
+  double d = micro_iterate(P, Psi, pfEx, d0, dg, ddg);
+  if (d < 0.0) d = 0.0; else if (d > 1.0) d = 1.0;
+  d = (d > d0) ? d : d0;
+  micro_terms(P, d, gn, gd, dg, ddg);
+  dout = d;
+  return gn / gd + 1.e-10;
 }
 
 // B_a^T v for a Voigt vector v (2D: xx,yy,xy; 3D: xx,yy,zz,xy,yz,zx), ShapeUtils.cpp:73-145
@@ -425,12 +448,24 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
     iso_update<RANK, S, SP>(P, eps, 1.0, r.d0, r.d1, r.d3, r.sig, sp, Psi);
   } else {
     if constexpr (FAM == FAM_PF_MIEHE) {
-      if (SP::model(P) == 4) {                          // MicroPhaseFractureModel.cpp:656-830 (general-tangent family only)
+      if (SP::model(P) >= 4) {                          // MicroPhaseFractureModel.cpp:656-830 (general-tangent family only)
         MicroOut mo;
-        double gphi = 1.0;
+        double gphi = 1.0, dhist = 0.0;
+        const bool ext = SP::model(P) != 4;               // MicroPhaseFractureExtModel.cpp:656-940, ...ExtItModel.cpp:712
+        double pfEx = pfX;
+        if (ext) {
+          if (SP::model(P) == 6 && write) { const double dd = pf - pfEx; err_acc += dd * dd; }
+          if (pfEx < 0.0) pfEx = 0.0; else if (pfEx > 1.0) pfEx = 1.0;
+        }
         auto gfun = [&](double Psi_raw, const double (&)[S]) {
           const double PsiM = (Psi_raw > P.psi0) ? Psi_raw : P.psi0;
-          gphi = micro_newton(P, PsiM, pf, H0, mo);
+          if (ext) {
+            gphi = micro_first_solve(P, PsiM, pfEx, H0, dhist);
+            micro_newton(P, PsiM, pf, dhist, H0, mo);
+          } else {
+            gphi = micro_newton(P, PsiM, pf, H0, H0, mo);
+            dhist = mo.d;
+          }
           return gphi;
         };
         if (SP::material(P) == 3) {
@@ -458,16 +493,18 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
           }
         }
         r.d0 = r.d1 = r.d3 = 0.0;
-        const double coef = mo.dgphi * mo.cdS;          // second elemMat1 term: dgphi * sigma+ (x) dphidStrain (:816)
+        if (!ext) {
+          const double coef = mo.dgphi * mo.cdS;        // second elemMat1 term: dgphi * sigma+ (x) dphidStrain (:816)
 #pragma unroll
-        for (int i = 0; i < S; i++)
+          for (int i = 0; i < S; i++)
 #pragma unroll
-          for (int j = 0; j < S; j++) r.D[i][j] += coef * (sp[i] * sp[j]);
+            for (int j = 0; j < S; j++) r.D[i][j] += coef * (sp[i] * sp[j]);
+        }
         if (P.strain != nullptr && write) P.strain[ipoint * srows + STR] = gphi;
-        if (write) P.hist_new[ipoint] = mo.d;
+        if (write) P.hist_new[ipoint] = dhist;
         r.c1 = P.alpha * (1.0 - mo.dphidd);             // K4 (:817)
         r.cf = P.alpha * (pf - mo.d);                   // f2 (:830)
-        r.dg = mo.dgphi * mo.dphidd;                    // K2 (:822)
+        r.dg = ext ? 0.0 : mo.dgphi * mo.dphidd;        // K2 (:822); the Ext variants have no elemMat2
         r.dgl = -P.alpha * mo.cdS;                      // K3 (:823)
         if constexpr (KEEP) {
 #pragma unroll
@@ -625,6 +662,10 @@ __device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, con
 #pragma unroll
       for (int a = 0; a < NPE; a++) { pf0 += tabN[ip * NPE + a] * E.phi0[a]; pfX += tabN[ip * NPE + a] * E.phiX[a]; }
     }
+    if (SP::model(P) >= 5) {
+#pragma unroll
+      for (int a = 0; a < NPE; a++) pfX += tabN[ip * NPE + a] * E.phiX[a];
+    }
   }
   ip_material<SH, FAM, KEEP, SP>(P, ipoint, eps, pf, pf0, pfX, H0, write, r, err_acc);
 }
@@ -757,7 +798,7 @@ __device__ __forceinline__ void compute_rowblock(const Params& P, int64_t e, int
 #pragma unroll
   for (int ip = 0; ip < NIP; ip++) H0v[ip] = 0.0;
   if constexpr (PF) {
-    if (SP::model(P) == 1 || SP::model(P) == 4) {
+    if (SP::model(P) == 1 || SP::model(P) >= 4) {
 #pragma unroll
       for (int ip = 0; ip < NIP; ip++) H0v[ip] = P.hist_pre[e * NIP + ip];
     }
@@ -996,7 +1037,7 @@ __global__ __launch_bounds__(SH::PBLOCK) void assemble_patch(const Params P) {
   ElemData<SH, PF> E;
   double H0 = 0.0;
   gather_elem<SH, PF>(P, cur.cn, E);
-  if constexpr (PF) { if (P.model == 1 || P.model == 4) H0 = P.hist_pre[cur.e * SH::NIP + (SH::SHARE ? la : 0)]; }
+  if constexpr (PF) { if (P.model == 1 || P.model >= 4) H0 = P.hist_pre[cur.e * SH::NIP + (SH::SHARE ? la : 0)]; }
 
   int cntsum = 0;
 #pragma unroll
@@ -1031,7 +1072,7 @@ __global__ __launch_bounds__(SH::PBLOCK) void assemble_patch(const Params P) {
       if (more) {                                            // gathers of the next pass fly during phase 2
         cur = nxt;
         gather_elem<SH, PF>(P, cur.cn, E);
-        if constexpr (PF) { if (P.model == 1 || P.model == 4) H0 = P.hist_pre[cur.e * SH::NIP + la]; }
+        if constexpr (PF) { if (P.model == 1 || P.model >= 4) H0 = P.hist_pre[cur.e * SH::NIP + la]; }
         const int k2 = kb + 2 * GPB + grp;
         if (kb + 2 * GPB < nelem) load_idx<NPE>(P, (int64_t)eb0 + min(k2, nelem - 1), la, k2 < nelem, nxt);
       }
@@ -1267,7 +1308,7 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
 #pragma unroll
     for (int k = 0; k < HALF; k++) H0v[k] = 0.0;
     if constexpr (PF) {
-      if (SP::model(P) == 1 || SP::model(P) == 4) {
+      if (SP::model(P) == 1 || SP::model(P) >= 4) {
 #pragma unroll
         for (int k = 0; k < HALF; k++) H0v[k] = P.hist_pre[e * NIP + half * HALF + k];
       }

@@ -413,6 +413,10 @@ class SolidAssemblyModel : public Model {
       myProps.find(sigmaT_, "tensileStrength"); myConf.set("tensileStrength", sigmaT_);
       if (kind_ == FA_MICRO_PHASE_FRACTURE) beta_ = 250.0;               // MicroPhaseFractureModel.cpp:269
       if (kind_ >= FA_PHASE_FRACTURE_EXT) { myProps.find(beta_, "penalty"); myConf.set("penalty", beta_); }
+      if (kind_ == FA_MICRO_PHASE_FRACTURE_EXTIT) {                      // MicroPhaseFractureExtItModel.cpp:262-268
+        oTol_ = 1.e-3; myProps.find(oTol_, "oTol"); myConf.set("oTol", oTol_);
+        double mi = oMaxIter_; if (myProps.find(mi, "oMaxIter")) oMaxIter_ = (int)mi; myConf.set("oMaxIter", (double)oMaxIter_);
+      }
     }
   }
   ~SolidAssemblyModel() override { if (ctx_) fa_destroy(ctx_); }
@@ -458,19 +462,25 @@ class SolidAssemblyModel : public Model {
     }
     if (action == Actions::GET_MATRIX2) throw Error(myName_, "GET_MATRIX2 is not served by the GPU assembly path");
     if (action == Actions::COMMIT) {
-      if (kind_ == FA_PHASE_FRACTURE || kind_ == FA_MICRO_PHASE_FRACTURE) check_(fa_commit(ctx_));   // newHist_.swap(preHist_)
+      if (kind_ == FA_PHASE_FRACTURE || kind_ >= FA_MICRO_PHASE_FRACTURE) check_(fa_commit(ctx_));   // newHist_.swap(preHist_)
       if (kind_ == FA_PHASE_FRACTURE_EXT) dt0_ = dt_;                    // PhaseFractureExtModel.cpp:450
       if (kind_ == FA_PHASE_FRACTURE_EXTIT) oIter_ = 0;                  // PhaseFractureExtItModel.cpp:480
       return true;
     }
-    if (kind_ == FA_PHASE_FRACTURE_EXTIT) {
+    if (kind_ == FA_PHASE_FRACTURE_EXTIT || kind_ == FA_MICRO_PHASE_FRACTURE_EXTIT) {
       if (action == "checkCommit") { checkCommit_(params, globdat); return true; }   // XActions::CHECK_COMMIT
+    } else if (kind_ == FA_MICRO_PHASE_FRACTURE_EXT) {
+      if (action == "checkCommit") return true;            // empty checkCommit_, MicroPhaseFractureExtModel.cpp:494-498
     } else if (action == Actions::CHECK_COMMIT) return true;
     if (action == Actions::SET_STEP_SIZE && (kind_ == FA_PHASE_FRACTURE_EXT || kind_ == FA_PHASE_FRACTURE_EXTIT)) {
       double dt, dt0; params.get(dt, ActionParams::STEP_SIZE); params.get(dt0, ActionParams::STEP_SIZE_0);
       dt_ = dt;
       if (kind_ == FA_PHASE_FRACTURE_EXTIT) dt0_ = dt0;                  // Ext ignores dt0 (PhaseFractureExtModel.cpp:1339)
       return false;                                                      // sic: both reference models fall through
+    }
+    if (action == Actions::SET_STEP_SIZE && kind_ >= FA_MICRO_PHASE_FRACTURE_EXT) {   // MicroPhaseFractureExtModel.cpp:1560-1577
+      params.get(dt_, ActionParams::STEP_SIZE); params.get(dt0_, ActionParams::STEP_SIZE_0);
+      return false;
     }
     return false;
   }
@@ -530,17 +540,39 @@ class SolidAssemblyModel : public Model {
         s00 = stateExt_.data();
       }
     }
+    const bool microExt = kind_ == FA_MICRO_PHASE_FRACTURE_EXT || kind_ == FA_MICRO_PHASE_FRACTURE_EXTIT;
+    if (microExt) {                                                      // MicroPhaseFractureExtModel.cpp:398-417, ExtIt :413-432
+      globdat.get(state0, Globdat::STATE_OLD); globdat.get(state00, Globdat::STATE_OLD_OLD);
+      int iterCount = 0; globdat.find(iterCount, Globdat::ITER_COUNT);
+      if (iterCount == 0 && !(kind_ == FA_MICRO_PHASE_FRACTURE_EXTIT && extFail_)) {
+        stateExt_.resize(state->size());
+        const double c = (dt_ + dt0_) / (dt0_ + 1.e-15);
+        for (size_t k = 0; k < state->size(); k++) stateExt_[k] = (*state00)[k] + c * ((*state0)[k] - (*state00)[k]);
+      }
+      if (stateExt_.size() != state->size()) throw Error(myName_, "stateExt_ has not been built (no call at iteration 0 yet)");
+      s00 = stateExt_.data();
+    }
     if ((int64_t)state->size() != fa_ndof(ctx_) || (int64_t)force->size() != fa_ndof(ctx_))
       throw Error(myName_, "state / force vector size does not match the DOF space");
     if (mb && (int64_t)mb->values.size() != fa_nnz(ctx_)) throw Error(myName_, "matrix structure differs from the one given at configure time");
     double err = 0.0;
     check_(fa_assemble_host(ctx_, state->data(), s0, s00, dt_, dt0_, mb ? mb->values.data() : nullptr, force->data(),
-                            kind_ == FA_PHASE_FRACTURE_EXTIT ? &err : nullptr, FA_ACCUMULATE));
-    if (kind_ == FA_PHASE_FRACTURE_EXTIT) errExt_ = err;
+                            (kind_ == FA_PHASE_FRACTURE_EXTIT || kind_ == FA_MICRO_PHASE_FRACTURE_EXTIT) ? &err : nullptr, FA_ACCUMULATE));
+    if (kind_ == FA_PHASE_FRACTURE_EXTIT || kind_ == FA_MICRO_PHASE_FRACTURE_EXTIT) errExt_ = err;
   }
 
   void checkCommit_(Properties& params, Properties& globdat) {          // PhaseFractureExtItModel.cpp:1335-1373
     Vector state; globdat.get(state, Globdat::STATE);
+    if (kind_ == FA_MICRO_PHASE_FRACTURE_EXTIT) {                        // MicroPhaseFractureExtItModel.cpp:1575-1613
+      if (std::sqrt(errExt_) > oTol_ && oIter_ < oMaxIter_) {
+        oIter_++;
+        params.set("discard", false); params.set("accept", false);
+        stateExt_ = *state;
+        extFail_ = true;
+      } else { extFail_ = false; oIter_ = 0; }
+      errExt_ = 0.0;
+      return;
+    }
     if (std::sqrt(errExt_) > 1.e-4) {
       oIter_++;
       params.set("discard", false); params.set("accept", false);
@@ -560,7 +592,7 @@ class SolidAssemblyModel : public Model {
   bool keepOffDiags_ = false;
   double gc_ = 2.7, l0_ = 0.015, sigmaT_ = 0.0, beta_ = 6500.0;   // PhaseFractureModel.cpp:253-263, Ext :247
   double dt_ = 0.0, dt0_ = 0.0, errExt_ = 0.0;
-  bool extFail_ = false; int oIter_ = 0;
+  bool extFail_ = false; int oIter_ = 0, oMaxIter_ = 5000; double oTol_ = 1.e-3;
   std::vector<double> stateExt_;
   fa_ctx* ctx_ = nullptr;
 };
@@ -577,7 +609,9 @@ void declareFalconSolidMechModels() {
   ModelFactory::declare("PhaseFracture", &newSolidModel<FA_PHASE_FRACTURE>);
   ModelFactory::declare("PhaseFractureExt", &newSolidModel<FA_PHASE_FRACTURE_EXT>);
   ModelFactory::declare("PhaseFractureExtIt", &newSolidModel<FA_PHASE_FRACTURE_EXTIT>);
-  ModelFactory::declare("MicroPhaseFracture", &newSolidModel<FA_MICRO_PHASE_FRACTURE>);   // first of the micromorphic variants
+  ModelFactory::declare("MicroPhaseFracture", &newSolidModel<FA_MICRO_PHASE_FRACTURE>);   // micromorphic variants
+  ModelFactory::declare("MicroPhaseFractureExt", &newSolidModel<FA_MICRO_PHASE_FRACTURE_EXT>);
+  ModelFactory::declare("MicroPhaseFractureExtIt", &newSolidModel<FA_MICRO_PHASE_FRACTURE_EXTIT>);
 }
 
 }  // namespace falcon_host

@@ -32,8 +32,13 @@ enum { FA_TRI3_G1 = 0, FA_TRI3_G3 = 1, FA_QUAD4_G2 = 2, FA_QUAD8_G3 = 3, FA_QUAD
 
 /* ModelFactory names, src/fem/solidmech/FalconSolidMechModels.cpp:10-22 */
 enum { FA_LINEAR_ELASTICITY = 0, FA_PHASE_FRACTURE = 1, FA_PHASE_FRACTURE_EXT = 2, FA_PHASE_FRACTURE_EXTIT = 3,
-       FA_MICRO_PHASE_FRACTURE = 4 /* "MicroPhaseFracture": micromorphic variant, MicroPhaseFractureModel.cpp:502-851;
-                                      history = local damage d (preHist_.phasef_), penalty default 250 */ };
+       FA_MICRO_PHASE_FRACTURE = 4, /* "MicroPhaseFracture": micromorphic variant, MicroPhaseFractureModel.cpp:502-851;
+                                      history = local damage d (preHist_.phasef_), penalty default 250 */
+       FA_MICRO_PHASE_FRACTURE_EXT = 5,   /* "MicroPhaseFractureExt", MicroPhaseFractureExtModel.cpp:523-952: g from
+                                      the damage solved for the extrapolated micromorphic variable; the caller passes
+                                      stateExt_ (:553-566) as state00; state0 / dt / dt0 are not read; penalty 6500 */
+       FA_MICRO_PHASE_FRACTURE_EXTIT = 6  /* "MicroPhaseFractureExtIt", MicroPhaseFractureExtItModel.cpp: the same plus
+                                      errExt_ = sum (pf - pfEx)^2 (:712) returned through err_ext */ };
 
 /* material.type, newMaterial, src/materials/Material.cpp:233-244 */
 enum { FA_HOOKE = 0, FA_AMOR_PHASE = 1, FA_BOURDIN_PHASE = 2, FA_MIEHE_PHASE = 3 };

@@ -831,6 +831,8 @@ int fo_assemble(const fo_config* cfg,
     if (isPF) for (int a = 0; a < phiCount; a++) phi[a] = state[phiDofs[a]];
     if ((model == FO_PHASE_FRACTURE_EXT || model == FO_PHASE_FRACTURE_EXTIT))
       for (int a = 0; a < phiCount; a++) { phi0[a] = state0[phiDofs[a]]; phiX[a] = state00[phiDofs[a]]; }
+    if (model == FO_MICRO_EXT || model == FO_MICRO_EXTIT)      /* phiEx = select(stateExt_, phiDofs) */
+      for (int a = 0; a < phiCount; a++) phiX[a] = state00[phiDofs[a]];
 
     memset(elemForce1, 0, sizeof elemForce1); memset(elemForce2, 0, sizeof elemForce2);
     if (mbuilder) {
@@ -962,6 +964,90 @@ int fo_assemble(const fo_config* cfg,
             for (int a = 0; a < phiCount; a++) for (int j = 0; j < dispCount; j++)
               elemMat3[a * dispCount + j] -= wip * alpha * (Nip[a] * sPB[j]);
           }
+        }
+        for (int a = 0; a < phiCount; a++) {
+          double s = 0.0;
+          for (int b = 0; b < phiCount; b++) s += BeBe[a * phiCount + b] * phi[b];
+          elemForce2[a] += wip * (alpha * (pf - d) * Nip[a] + c2 * s);
+        }
+      } else if (model == FO_MICRO_EXT || model == FO_MICRO_EXTIT) {
+        /* MicroPhaseFractureExtModel.cpp:656-940; ExtIt differs by errExt_ only (MicroPhaseFractureExtItModel.cpp:712) */
+        const double* Nip = sh.N[ip];
+        const double p_ = fr.p, a1_ = fr.a1, a2_ = fr.a2, a3_ = fr.a3;
+        const double alpha = beta_ * gc_ / l0_;
+        const double pf = dotn(phiCount, Nip, phi);
+        double pfEx = dotn(phiCount, Nip, phiX);
+        if (model == FO_MICRO_EXTIT) errExt += pow(pf - pfEx, 2.0);
+        if (pfEx < 0.0) pfEx = 0.0; else if (pfEx > 1.0) pfEx = 1.0;
+        double Psi;
+        if (material_update_split(cfg, rank, strain, stressP, stressN, stiffP, stiffN, &Psi)) return -1;
+        Psi = (Psi > Psi0_) ? Psi : Psi0_;
+        const double d0 = hist_pre[ipoint];
+        double d = d0;
+        double gphi_n, gphi_d, dgphi_n, dgphi_d, ddgphi_n, ddgphi_d, dgphi, ddgphi, dw, ddw, Res, J;
+#define MICRO_TERMS(target)                                                                              \
+        gphi_n = pow(1.0 - d, p_);                                                                       \
+        gphi_d = gphi_n + a1_ * d + a1_ * a2_ * d * d + a1_ * a2_ * a3_ * d * d * d;                     \
+        dgphi_n = -p_ * (pow(1.0 - d, p_ - 1.0));                                                        \
+        dgphi_d = dgphi_n + a1_ + 2.0 * a1_ * a2_ * d + 3.0 * a1_ * a2_ * a3_ * d * d;                   \
+        ddgphi_n = p_ * (p_ - 1.0) * (pow(1.0 - d, p_ - 2.0));                                           \
+        ddgphi_d = ddgphi_n + 2.0 * a1_ * a2_ + 6.0 * a1_ * a2_ * a3_ * d;                               \
+        dgphi = (dgphi_n * gphi_d - gphi_n * dgphi_d) / (gphi_d * gphi_d);                               \
+        ddgphi = ((ddgphi_n * gphi_d - gphi_n * ddgphi_d) * gphi_d - 2.0 *                               \
+                  (dgphi_n * gphi_d - gphi_n * dgphi_d) * dgphi_d) / (gphi_d * gphi_d * gphi_d);         \
+        dw = eta_ + 2.0 * (1.0 - eta_) * d;                                                              \
+        ddw = 2.0 * (1.0 - eta_);                                                                        \
+        Res = dgphi * Psi + gc_ / (cw_ * l0_) * dw + alpha * (d - (target));                             \
+        J = ddgphi * Psi + gc_ / (cw_ * l0_) * ddw + alpha;
+        MICRO_TERMS(pfEx)
+        int iter = 0;
+        while (fabs(Res) > 1.e-4 && iter < 100) { iter += 1; d -= Res / J; MICRO_TERMS(pfEx) }
+        if (d < 0.0) d = 0.0; else if (d > 1.0) d = 1.0;
+        d = (d > d0) ? d : d0;
+        gphi_n = pow(1.0 - d, p_);
+        gphi_d = gphi_n + a1_ * d + a1_ * a2_ * d * d + a1_ * a2_ * a3_ * d * d * d;
+        const double gphi = gphi_n / gphi_d + 1.e-10;
+        if (strain_cache) strain_cache[ipoint * srows + strCount] = gphi;
+        hist_new[ipoint] = d;
+        for (int c = 0; c < strCount; c++) {
+          stress[c] = gphi * stressP[c] + stressN[c];
+          for (int k = 0; k < strCount; k++) stiff[c * strCount + k] = gphi * stiffP[c * strCount + k] + stiffN[c * strCount + k];
+        }
+        MICRO_TERMS(pf)                                   /* second solve, for the current micromorphic variable */
+        iter = 0;
+        while (fabs(Res) > 1.e-4 && iter < 100) { iter += 1; d -= Res / J; MICRO_TERMS(pf) }
+#undef MICRO_TERMS
+        double dphidd = 0.0;
+        if (d > d0) {
+          const double den = ddgphi * Psi + gc_ / (cw_ * l0_) * ddw + alpha;
+          for (int c = 0; c < strCount; c++) dphidStrain[c] = -(dgphi) / den * stressP[c];
+          dphidd = alpha / den;
+        } else if (d < 0.0) {
+          d = 0.0;
+          for (int c = 0; c < strCount; c++) dphidStrain[c] = 0.0;
+        } else if (d > 1.0) {
+          d = 1.0;                                        /* dphidStrain keeps its previous contents */
+          g_micro_stale++;
+        } else {
+          d = d0;
+          for (int c = 0; c < strCount; c++) dphidStrain[c] = 0.0;
+        }
+        for (int a = 0; a < phiCount; a++) for (int b = 0; b < phiCount; b++) {
+          double s = 0.0;
+          for (int i = 0; i < rank; i++) s += grads[ip][a][i] * grads[ip][b][i];
+          BeBe[a * phiCount + b] = s;
+        }
+        const double c2 = 2.0 * gc_ * l0_ / cw_;
+        if (mbuilder) {
+          for (int j = 0; j < dispCount; j++) {            /* matmul(dphidStrain, bd) */
+            double s = 0.0;
+            for (int c = 0; c < strCount; c++) s += dphidStrain[c] * bd[c * dispCount + j];
+            sPB[j] = s;
+          }
+          for (int a = 0; a < phiCount; a++) for (int j = 0; j < dispCount; j++)
+            elemMat3[a * dispCount + j] -= wip * alpha * (Nip[a] * sPB[j]);
+          for (int a = 0; a < phiCount; a++) for (int b = 0; b < phiCount; b++)
+            elemMat4[a * phiCount + b] += wip * (alpha * (1.0 - dphidd) * (Nip[a] * Nip[b]) + c2 * BeBe[a * phiCount + b]);
         }
         for (int a = 0; a < phiCount; a++) {
           double s = 0.0;

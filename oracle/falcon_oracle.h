@@ -43,7 +43,9 @@ enum {
   FO_PHASE_FRACTURE      = 1,
   FO_PHASE_FRACTURE_EXT  = 2,
   FO_PHASE_FRACTURE_EXTIT= 3,
-  FO_MICRO_PHASE_FRACTURE= 4   /* MicroPhaseFractureModel.cpp:502-851 (micromorphic: local damage d by Newton) */
+  FO_MICRO_PHASE_FRACTURE= 4,  /* MicroPhaseFractureModel.cpp:502-851 (micromorphic: local damage d by Newton) */
+  FO_MICRO_EXT           = 5,  /* MicroPhaseFractureExtModel.cpp:523-952: g from the extrapolated micromorphic variable */
+  FO_MICRO_EXTIT         = 6   /* MicroPhaseFractureExtItModel.cpp: the same + errExt_ (pass stateExt_ as state00 for both) */
 };
 
 /* material ids: newMaterial, src/materials/Material.cpp:233-244 */

@@ -16,7 +16,9 @@ _LIB = os.path.join(_HERE, "libfalcon_oracle.so")
 # shape ids
 TRI3_G1, TRI3_G3, QUAD4_G2, QUAD8_G3, QUAD8_G2, TRI6_G3, HEX8_G2, HEX20_G3, HEX20_G2 = range(9)
 # models
-LINEAR_ELASTICITY, PHASE_FRACTURE, PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT, MICRO_PHASE_FRACTURE = range(5)
+(LINEAR_ELASTICITY, PHASE_FRACTURE, PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT, MICRO_PHASE_FRACTURE, MICRO_EXT,
+ MICRO_EXTIT) = range(7)
+HISTORY_MODELS = (PHASE_FRACTURE, MICRO_PHASE_FRACTURE, MICRO_EXT, MICRO_EXTIT)
 # materials
 HOOKE, AMOR, BOURDIN, MIEHE = range(4)
 PLANE_STRAIN, PLANE_STRESS = 0, 1
@@ -120,7 +122,7 @@ def keep_code(cfg):
     """keep_off_diags code of fo_pattern for the WRITTEN pattern of this model."""
     if cfg.model in (PHASE_FRACTURE, MICRO_PHASE_FRACTURE):
         return 1 if cfg.keep_off_diags else 0
-    if cfg.model in (PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT):
+    if cfg.model in (PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT, MICRO_EXT, MICRO_EXTIT):
         return 2
     return 0
 
@@ -156,7 +158,7 @@ def assemble(cfg, coords, conn, row_ptr, col_idx, state, state0=None, state00=No
         K = np.zeros(row_ptr[-1])
     if f is None:
         f = np.zeros(ndof)
-    if cfg.model in (PHASE_FRACTURE, MICRO_PHASE_FRACTURE):
+    if cfg.model in HISTORY_MODELS:
         if hist_pre is None:     # preHist_.H0_ = Psi0_ (PhaseFractureModel.cpp:359); preHist_.phasef_ = 0 (MicroPhaseFractureModel.cpp:359)
             hist_pre = np.full(nel * nip, psi0(cfg) if cfg.model == PHASE_FRACTURE else 0.0)
         hist_pre = np.ascontiguousarray(hist_pre, dtype=np.float64)

@@ -27,6 +27,8 @@ CASES = [  # name, shape, mesh, model, material, keep, frac, extra config
     ("extit_tri6_miehe", po.TRI6_G3, lambda: meshgen.grid_tri6(2, 2), po.PHASE_FRACTURE_EXTIT, po.MIEHE, 0, po.AT2, {}),
     ("micro_quad4_miehe", po.QUAD4_G2, lambda: meshgen.grid_quad4(3, 3), po.MICRO_PHASE_FRACTURE, po.MIEHE, 1, po.AT2, dict(beta=250.0)),
     ("micro_hex8_bourdin", po.HEX8_G2, lambda: meshgen.grid_hex8(2, 1, 2), po.MICRO_PHASE_FRACTURE, po.BOURDIN, 0, po.AT2, dict(beta=250.0)),
+    ("microext_quad4_miehe", po.QUAD4_G2, lambda: meshgen.grid_quad4(3, 3), po.MICRO_EXT, po.MIEHE, 0, po.AT2, {}),
+    ("microextit_tri3_bourdin", po.TRI3_G1, lambda: meshgen.grid_tri3(3, 3), po.MICRO_EXTIT, po.BOURDIN, 0, po.AT1, dict(beta=250.0)),
 ]
 
 
@@ -48,11 +50,12 @@ def build(case):
         st0[rank::nd] += rng.uniform(-0.02, 0.02, coords.shape[0])
         st00[rank::nd] += rng.uniform(-0.02, 0.02, coords.shape[0])
     info = po.shape_info(shape)
-    H0 = rng.uniform(0, 2e-3 if model != po.MICRO_PHASE_FRACTURE else 0.4, conn.shape[0] * info[2])   # H0_ or committed local damage
+    H0 = rng.uniform(0, 2e-3 if model < po.MICRO_PHASE_FRACTURE else 0.4, conn.shape[0] * info[2])   # H0_ or committed local damage
     rp, ci = po.pattern(coords.shape[0], conn, nd, rank, po.PATTERN_FULL, po.keep_code(cfg))
     ext = model in (po.PHASE_FRACTURE_EXT, po.PHASE_FRACTURE_EXTIT)
-    r = po.assemble(cfg, coords, conn, rp, ci, st, state0=st0 if ext else None, state00=st00 if ext else None, dt=0.7, dt0=0.4,
-                    hist_pre=H0 if model in (po.PHASE_FRACTURE, po.MICRO_PHASE_FRACTURE) else None, want_strain=True)
+    mext = model in (po.MICRO_EXT, po.MICRO_EXTIT)                       # state00 carries stateExt_
+    r = po.assemble(cfg, coords, conn, rp, ci, st, state0=st0 if ext else None, state00=st00 if (ext or mext) else None, dt=0.7, dt0=0.4,
+                    hist_pre=H0 if model in po.HISTORY_MODELS else None, want_strain=True)
     out = dict(shape=shape, model=model, material=material, coords=coords, conn=conn, state=st, state0=st0, state00=st00,
                hist_pre=H0, row_ptr=rp, col_idx=ci, K=r["K"], f=r["f"], strain=r["strain"],
                hist_new=r["hist_new"] if r["hist_new"] is not None else np.zeros(0), err_ext=np.float64(r["err_ext"]),

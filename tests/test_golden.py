@@ -31,11 +31,12 @@ def test_oracle_reproduces_goldens(name):
     rp, ci = po.pattern(d["coords"].shape[0], d["conn"], po.ndof_per_node(model, rank), rank, po.PATTERN_FULL, po.keep_code(cfg))
     assert np.array_equal(rp, d["row_ptr"]) and np.array_equal(ci, d["col_idx"])
     ext = model in (po.PHASE_FRACTURE_EXT, po.PHASE_FRACTURE_EXTIT)
+    mext = model in (po.MICRO_EXT, po.MICRO_EXTIT)
     r = po.assemble(cfg, d["coords"], d["conn"], rp, ci, d["state"], state0=d["state0"] if ext else None,
-                    state00=d["state00"] if ext else None, dt=0.7, dt0=0.4,
-                    hist_pre=d["hist_pre"] if model in (po.PHASE_FRACTURE, po.MICRO_PHASE_FRACTURE) else None, want_strain=True)
+                    state00=d["state00"] if (ext or mext) else None, dt=0.7, dt0=0.4,
+                    hist_pre=d["hist_pre"] if model in po.HISTORY_MODELS else None, want_strain=True)
     assert np.array_equal(r["K"], d["K"]) and np.array_equal(r["f"], d["f"]) and np.array_equal(r["strain"], d["strain"])
-    if model in (po.PHASE_FRACTURE, po.MICRO_PHASE_FRACTURE):
+    if model in po.HISTORY_MODELS:
         assert np.array_equal(r["hist_new"], d["hist_new"])
     assert r["err_ext"] == float(d["err_ext"])
 
@@ -54,16 +55,18 @@ def test_hip_path_reproduces_goldens(name):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     K = torch.full((asm.nnz,), 7.0, dtype=torch.float64, device=dev); f = torch.full((asm.ndof,), -3.0, dtype=torch.float64, device=dev)
     err = torch.zeros(1, dtype=torch.float64, device=dev)
-    if model in (capi.PHASE_FRACTURE, capi.MICRO_PHASE_FRACTURE):
+    hist = model == capi.PHASE_FRACTURE or model >= capi.MICRO_PHASE_FRACTURE
+    if hist:
         asm.set_history(0, d["hist_pre"])
     ext = model in (capi.PHASE_FRACTURE_EXT, capi.PHASE_FRACTURE_EXTIT)
-    asm.assemble(t(d["state"]), K, f, state0=t(d["state0"]) if ext else None, state00=t(d["state00"]) if ext else None,
+    mext = model in (capi.MICRO_PHASE_FRACTURE_EXT, capi.MICRO_PHASE_FRACTURE_EXTIT)
+    asm.assemble(t(d["state"]), K, f, state0=t(d["state0"]) if ext else None, state00=t(d["state00"]) if (ext or mext) else None,
                  dt=0.7, dt0=0.4, err_ext=err, flags=capi.OVERWRITE | capi.STORE_STRAIN)
     torch.cuda.synchronize()
     assert rel_rowmax_err(rp, K.cpu().numpy(), d["K"]) < 1e-12
     assert np.abs(f.cpu().numpy() - d["f"]).max() < 1e-12 * np.abs(d["f"]).max()
     assert np.abs(asm.get_strain_cache() - d["strain"]).max() < 1e-12 * np.abs(d["strain"]).max()
-    if model in (capi.PHASE_FRACTURE, capi.MICRO_PHASE_FRACTURE):
+    if hist:
         assert np.abs(asm.get_history(1) - d["hist_new"]).max() < 1e-12 * np.abs(d["hist_new"]).max()
-    if model == capi.PHASE_FRACTURE_EXTIT:
+    if model in (capi.PHASE_FRACTURE_EXTIT, capi.MICRO_PHASE_FRACTURE_EXTIT):
         assert abs(err.item() - float(d["err_ext"])) < 1e-12 * float(d["err_ext"])

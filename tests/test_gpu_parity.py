@@ -384,13 +384,13 @@ ALL_SHAPES = [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2] + HIGH_ORDER
 
 
 def run_micro(shape, material, keep, *, flags=capi.OVERWRITE, want_K=True, commit=False, frac=capi.AT2, sigma_t=0.0,
-              young=210.0, gc=2.7e-3, l0=0.2, tol=TOL):
+              young=210.0, gc=2.7e-3, l0=0.2, tol=TOL, model=capi.MICRO_PHASE_FRACTURE, beta=250.0):
     import torch
-    coords, conn, st, kw, cfg = make_case(shape, capi.MICRO_PHASE_FRACTURE, material, keep, frac=frac, sigma_t=sigma_t,
+    coords, conn, st, kw, cfg = make_case(shape, model, material, keep, frac=frac, sigma_t=sigma_t,
                                           young=young, gc=gc, l0=l0)
-    kw["beta"] = 250.0
-    cfg = po.make_config(shape, po.MICRO_PHASE_FRACTURE, material, **kw)
-    asm = capi.Assembler(shape, capi.MICRO_PHASE_FRACTURE, material, coords, conn, **kw)
+    kw["beta"] = beta
+    cfg = po.make_config(shape, model, material, **kw)
+    asm = capi.Assembler(shape, model, material, coords, conn, **kw)
     rp, ci = asm.pattern()
     rpo, cio = po.pattern(coords.shape[0], conn, asm.ndofpn, coords.shape[1], po.PATTERN_FULL, po.keep_code(cfg))
     assert np.array_equal(rp, rpo) and np.array_equal(ci, cio)
@@ -400,9 +400,18 @@ def run_micro(shape, material, keep, *, flags=capi.OVERWRITE, want_K=True, commi
     dev = torch.device("cuda", 0)
     K = torch.full((asm.nnz,), 3.0, dtype=torch.float64, device=dev) if want_K else None
     f = torch.full((asm.ndof,), -2.0, dtype=torch.float64, device=dev)
-    asm.assemble(torch.from_numpy(st).to(dev), K, f, flags=flags | capi.STORE_STRAIN)
+    ext = model != capi.MICRO_PHASE_FRACTURE
+    stx = None
+    if ext:                                                       # stateExt_: the caller's extrapolation, some of it outside [0,1]
+        stx = st.copy()
+        stx[asm.ndofpn - 1::asm.ndofpn] += rng.uniform(-0.05, 0.05, coords.shape[0])
+        stx[asm.ndofpn - 1::asm.ndofpn][::7] = -0.01
+        stx[asm.ndofpn - 1::asm.ndofpn][3::11] = 1.02
+    err = torch.full((1,), 7.0, dtype=torch.float64, device=dev) if model == capi.MICRO_PHASE_FRACTURE_EXTIT else None
+    asm.assemble(torch.from_numpy(st).to(dev), K, f, state00=None if stx is None else torch.from_numpy(stx).to(dev),
+                 err_ext=err, flags=flags | capi.STORE_STRAIN)
     torch.cuda.synchronize()
-    ref = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=d0, want_K=want_K, want_strain=True)
+    ref = po.assemble(cfg, coords, conn, rp, ci, st, state00=stx, hist_pre=d0, want_K=want_K, want_strain=True)
     assert ref["micro_stale_hits"] == 0
     loading = (ref["hist_new"] > d0).mean()
     assert 0.05 < loading < 0.95                                  # both branches of :738-782 are exercised
@@ -411,6 +420,8 @@ def run_micro(shape, material, keep, *, flags=capi.OVERWRITE, want_K=True, commi
     assert vec_err(f.cpu().numpy(), ref["f"]) < tol
     assert np.abs(asm.get_history(1) - ref["hist_new"]).max() < tol
     assert np.abs(asm.get_strain_cache() - ref["strain"]).max() < tol * np.abs(ref["strain"]).max()
+    if err is not None:
+        assert ref["err_ext"] > 0 and abs(err.item() - ref["err_ext"]) < tol * ref["err_ext"]
     if commit:                                                    # COMMIT: newHist_.phasef_.swap(preHist_.phasef_) (:458-463)
         asm.commit()
         assert np.abs(asm.get_history(0) - ref["hist_new"]).max() < tol
@@ -439,3 +450,31 @@ def test_micro_amor_is_refused():
     coords, conn = meshgen.grid_quad4(3, 3)
     with pytest.raises(capi.FaError, match="serial Gauss-point order"):
         capi.Assembler(capi.QUAD4_G2, capi.MICRO_PHASE_FRACTURE, capi.AMOR_PHASE, coords, conn)
+
+
+# ---- MicroPhaseFractureExt / MicroPhaseFractureExtIt ----
+@pytest.mark.parametrize("shape", ALL_SHAPES)
+@pytest.mark.parametrize("model", [capi.MICRO_PHASE_FRACTURE_EXT, capi.MICRO_PHASE_FRACTURE_EXTIT])
+def test_micro_ext_variants(shape, model):
+    """Two local Newton solves per Gauss point (MicroPhaseFractureExtModel.cpp:728-850): the first, for the
+    extrapolated micromorphic variable (stateExt_, handed over as state00), gives the degradation and the history;
+    the second, for the current one, gives the K3 / K4 / f2 coefficients.  No K2 block (pattern keep code 2)."""
+    material = capi.MIEHE_PHASE if shape in (capi.QUAD4_G2, capi.TRI6_G3, capi.HEX20_G2) else capi.BOURDIN_PHASE
+    run_micro(shape, material, keep=0, model=model, commit=True)
+    run_micro(shape, material, keep=0, model=model, want_K=False, beta=6500.0)
+
+
+@pytest.mark.parametrize("material", [capi.BOURDIN_PHASE, capi.MIEHE_PHASE])
+def test_micro_ext_quad4_both_materials(material):
+    run_micro(capi.QUAD4_G2, material, keep=0, model=capi.MICRO_PHASE_FRACTURE_EXTIT, beta=6500.0)
+    run_micro(capi.HEX8_G2, material, keep=0, model=capi.MICRO_PHASE_FRACTURE_EXT, flags=capi.OVERWRITE | capi.DETERMINISTIC)
+
+
+def test_micro_ext_needs_state_ext():
+    import torch
+    coords, conn = meshgen.grid_quad4(3, 3)
+    asm = capi.Assembler(capi.QUAD4_G2, capi.MICRO_PHASE_FRACTURE_EXT, capi.MIEHE_PHASE, coords, conn)
+    dev = torch.device("cuda", 0)
+    st = torch.zeros(asm.ndof, dtype=torch.float64, device=dev); f = torch.zeros_like(st)
+    with pytest.raises(capi.FaError, match="stateExt_"):
+        asm.assemble(st, None, f, flags=capi.OVERWRITE)

@@ -149,3 +149,57 @@ def test_micro_phase_fracture_through_take_action():
     r2 = po.assemble(cfg, coords, conn, rp, ci, st2, hist_pre=r1["hist_new"], want_K=False)
     assert ok and np.abs(f2 - r2["f"]).max() < 1e-12 * np.abs(f2).max()
     assert case.take_action("setStepSize", step=0.5, step0=0.1)[0] is False
+
+
+@pytest.mark.gpu
+def test_micro_ext_models_through_take_action():
+    """"MicroPhaseFractureExt" / "MicroPhaseFractureExtIt": stateExt_ is built at solver iteration 0 from
+    state0 / state00 and the step sizes (MicroPhaseFractureExtModel.cpp:408-417), COMMIT swaps the local damage, the
+    ExtIt variant replaces stateExt_ by the state while sqrt(errExt_) > oTol (…ExtItModel.cpp:1588-1612)."""
+    from falcon_amd import meshgen
+    from oracle import pyoracle as po
+    coords, conn = meshgen.grid_quad4(6, 5)
+    coords = meshgen.distort(coords, conn, 0.1)
+    mesh = "<Nodes>\n" + "".join(f"{i + 1} {x:.17g} {y:.17g};\n" for i, (x, y) in enumerate(coords)) + "</Nodes>\n"
+    mesh += "<Elements>\n" + "".join(f"{e + 1} " + " ".join(str(n + 1) for n in c) + ";\n" for e, c in enumerate(conn))
+    mesh += "</Elements>\n<ElementGroup name=\"all\">\n{" + ",".join(str(e + 1) for e in range(len(conn))) + "}\n</ElementGroup>\n"
+    pro = '''model = "Matrix" { matrix.type = "FEM"; model = "Multi" { models = ["bulk"];
+      bulk = "%s" { elements = "all"; shape = { type = "Quad4"; intScheme = "Gauss2*Gauss2"; };
+        material = { type = "MiehePhase"; rank = 2; state = "PLANE_STRAIN"; young = 210.0; poisson = 0.3; };
+        fractureType = "at2"; griffithEnergy = 2.7e-3; lengthScale = 0.2; %s }; }; };'''
+    st = meshgen.smooth_state(coords, 3, amp=5e-3, noise=1e-4, l0=0.3)
+    st0 = st.copy(); st0[2::3] -= 0.004
+    st00 = st.copy(); st00[2::3] -= 0.01
+    kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2, beta=6500.0)          # penalty default 6500 (:262)
+    ext = st00 + (0.5 + 0.25) / (0.25 + 1e-15) * (st0 - st00)
+
+    case = hostapi.Case(pro % ("MicroPhaseFractureExt", ""), mesh)
+    assert case.model_type == "MicroPhaseFractureExt"
+    rp, ci = case.pattern()
+    cfg = po.make_config(po.QUAD4_G2, po.MICRO_EXT, po.MIEHE, **kw)
+    assert case.take_action("setStepSize", step=0.5, step0=0.25)[0] is False
+    ok, K, f = case.take_action("GET_MATRIX0", state=st, state0=st0, state00=st00, iter_count=0)
+    r1 = po.assemble(cfg, coords, conn, rp, ci, st, state00=ext)
+    assert ok and np.abs(K - r1["K"]).max() < 1e-12 * np.abs(K).max() and np.abs(f - r1["f"]).max() < 1e-12 * np.abs(f).max()
+    assert case.take_action("checkCommit", state=st)[0] and case.take_action("COMMIT")[0]
+    # iteration 1 of the next step: stateExt_ is kept, the committed damage is the history
+    st2 = st * 0.5
+    ok, _, f2 = case.take_action("GET_INT_VECTOR", state=st2, state0=st, state00=st0, iter_count=1)
+    r2 = po.assemble(cfg, coords, conn, rp, ci, st2, state00=ext, hist_pre=r1["hist_new"], want_K=False)
+    assert ok and np.abs(f2 - r2["f"]).max() < 1e-12 * np.abs(f2).max()
+
+    case = hostapi.Case(pro % ("MicroPhaseFractureExtIt", "oTol = 1.e-3; oMaxIter = 2;"), mesh)
+    cfg = po.make_config(po.QUAD4_G2, po.MICRO_EXTIT, po.MIEHE, **kw)
+    case.take_action("setStepSize", step=0.5, step0=0.25)
+    ok, K, f = case.take_action("GET_MATRIX0", state=st, state0=st0, state00=st00, iter_count=0)
+    r = po.assemble(cfg, coords, conn, rp, ci, st, state00=ext)
+    assert ok and np.abs(K - r["K"]).max() < 1e-12 * np.abs(K).max() and np.abs(f - r["f"]).max() < 1e-12 * np.abs(f).max()
+    assert np.sqrt(r["err_ext"]) > 1e-3
+    assert case.take_action("checkCommit", state=st)[0]                 # not converged: stateExt_ = state, extFail_
+    ok, _, f = case.take_action("GET_INT_VECTOR", state=st, state0=st0, state00=st00, iter_count=0)
+    r = po.assemble(cfg, coords, conn, rp, ci, st, state00=st, want_K=False)
+    assert ok and np.abs(f - r["f"]).max() < 1e-12 * np.abs(f).max() and r["err_ext"] == 0.0
+    assert case.take_action("checkCommit", state=st)[0]                 # converged: extFail_ cleared, extrapolation is rebuilt
+    ok, _, f = case.take_action("GET_INT_VECTOR", state=st, state0=st0, state00=st00, iter_count=0)
+    r = po.assemble(cfg, coords, conn, rp, ci, st, state00=ext, want_K=False)
+    assert ok and np.abs(f - r["f"]).max() < 1e-12 * np.abs(f).max()

@@ -346,3 +346,34 @@ def test_micro_unloading_and_limits():
     hist = np.full(conn.shape[0] * 4, 0.3)
     r2 = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=hist)
     assert np.all(r2["hist_new"] == 0.3)
+
+
+# ---- MicroPhaseFractureExt / ExtIt (MicroPhaseFractureExtModel.cpp:523-952) ----
+def test_micro_ext_reduces_to_plain_micro_and_blocks():
+    """With stateExt_ equal to the state both Newton solves see the same target: the Ext model's f_int and damage are
+    the plain micromorphic model's (up to the 1e-10 floor on g); errExt_ is then 0 for ExtIt; K has no K2 block and
+    its K1 block is the secant one (g D+ + D-), i.e. K1 of the plain model minus the rank-one term."""
+    coords, conn = meshgen.grid_quad4(5, 4)
+    coords = meshgen.distort(coords, conn, 0.1)
+    st = meshgen.smooth_state(coords, 3, amp=5e-3, noise=1e-4, l0=0.3)
+    kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2, beta=250.0, keep_off_diags=1)
+    rp, ci = po.pattern(coords.shape[0], conn, 3, 2, po.PATTERN_FULL, 0)
+    plain = po.assemble(po.make_config(po.QUAD4_G2, po.MICRO_PHASE_FRACTURE, po.MIEHE, **kw), coords, conn, rp, ci, st)
+    for model in (po.MICRO_EXT, po.MICRO_EXTIT):
+        r = po.assemble(po.make_config(po.QUAD4_G2, model, po.MIEHE, **kw), coords, conn, rp, ci, st, state00=st)
+        assert np.abs(r["hist_new"] - plain["hist_new"]).max() == 0.0
+        assert np.abs(r["f"] - plain["f"]).max() < 1e-8 * np.abs(plain["f"]).max()
+        assert r["err_ext"] == 0.0
+        import scipy.sparse as sp
+        A = sp.csr_matrix((r["K"], ci, rp)).toarray(); B = sp.csr_matrix((plain["K"], ci, rp)).toarray()
+        u = np.arange(A.shape[0]) % 3 != 2
+        assert np.abs(A[np.ix_(u, ~u)]).max() == 0.0 and np.abs(B[np.ix_(u, ~u)]).max() > 0.0      # no elemMat2
+        assert np.abs(A[np.ix_(~u, u)] - B[np.ix_(~u, u)]).max() < 1e-8 * np.abs(B).max()           # same K3
+        assert np.abs(A[np.ix_(~u, ~u)] - B[np.ix_(~u, ~u)]).max() < 1e-8 * np.abs(B).max()         # same K4
+    # a different extrapolation changes g (first solve) but not the coefficients of the second solve
+    ext = st.copy(); ext[2::3] += 0.05
+    r = po.assemble(po.make_config(po.QUAD4_G2, po.MICRO_EXTIT, po.MIEHE, **kw), coords, conn, rp, ci, st, state00=ext)
+    nn = coords.shape[0]
+    assert r["err_ext"] > 0 and np.all(r["hist_new"] >= plain["hist_new"])
+    # errExt_ = sum over Gauss points of (pf - pfEx)^2 = 0.05^2 * number of points (partition of unity)
+    assert abs(r["err_ext"] - 0.05 ** 2 * conn.shape[0] * 4) < 1e-12
