@@ -64,6 +64,15 @@ def workload(name, n, capi, material="amor", keep=False):
         return dict(desc=f"cfg5: {n}^3 hex20 linear-elastic block (Hooke), Gauss{'3' if g3 else '2'}^3",
                     shape=capi.HEX20_G3 if g3 else capi.HEX20_G2, model=capi.LINEAR_ELASTICITY, material=capi.HOOKE,
                     dims=(n, n, n), h=1.0 / n, written_per_pair=9, kw=dict(young=210e3, poisson=0.3))
+    if name in ("quad8", "quad8g2", "tri6"):   # higher-order 2-D shapes, phase-field fracture like cfg3
+        n = n or 1000
+        shape, gen, sname = {"quad8": (capi.QUAD8_G3, "grid_quad8", "Quad8 Gauss3*Gauss3"),
+                             "quad8g2": (capi.QUAD8_G2, "grid_quad8", "Quad8 Gauss2*Gauss2"),
+                             "tri6": (capi.TRI6_G3, "grid_tri6", "Triangle6 Gauss3")}[name]
+        return dict(desc=f"{name}: {n}x{n} {sname}, phase-field fracture (u-phi), AT2, {mname}, "
+                         f"keepOffDiags={'true' if keep else 'false'}", shape=shape, model=capi.PHASE_FRACTURE,
+                    material=mat, dims=(n, n), h=1.0 / n, written_per_pair=9 if keep else 5, gen=gen,
+                    kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=keep))
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -156,10 +165,12 @@ def main():
     if rk == 2:
         nx, ny = wl["dims"]
         if world > 1:      # weak scaling: every rank gets a full-size strip, stacked in y
+            if wl.get("gen"):
+                raise SystemExit("multi-GPU bench is implemented for the Quad4 strip partition")
             part = StripPartition(nx, ny * world, world, rank, 3 if wl["model"] else 2)
             coords, conn = part.local_mesh(meshgen, wl["h"])
         else:
-            coords, conn = meshgen.grid_quad4(nx, ny, nx * wl["h"], ny * wl["h"])
+            coords, conn = getattr(meshgen, wl.get("gen", "grid_quad4"))(nx, ny, nx * wl["h"], ny * wl["h"])
     else:
         nx, ny, nz = wl["dims"]
         gen = meshgen.grid_hex20 if wl["shape"] in (capi.HEX20_G3, capi.HEX20_G2) else meshgen.grid_hex8
@@ -169,7 +180,6 @@ def main():
     kind = capi.PATTERN_FULL if args.pattern == "full" else capi.PATTERN_WRITTEN
     asm = capi.Assembler(wl["shape"], wl["model"], wl["material"], coords, conn, pattern_kind=kind,
                          device=local_rank, **wl["kw"])
-    assert asm.uses_row_kernel or wl["shape"] in (capi.HEX20_G3, capi.HEX20_G2)
     state = torch.from_numpy(meshgen.smooth_state(coords, asm.ndofpn, seed=12345 + rank)).to(dev)
     del coords
     want_K = not args.force_only

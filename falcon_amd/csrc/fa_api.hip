@@ -19,6 +19,7 @@
 #include "../../include/falcon_assemble.h"
 #include "fa_internal.h"
 #include "fa_patches.h"
+#include "fa_tiles.h"
 
 namespace {
 
@@ -254,8 +255,8 @@ struct fa_ctx {
   bool rows_path = false, own_pattern = false, coop = false;
   int ngrid_coop = 0;
   int nwg = 0, max_valence = 0, ngrid_generic = 0, block = 0, npatch = 0, plds = 0;
-  bool patch_path = false, pair_path = false;
-  int ntile2 = 0;
+  bool patch_path = false, pair_path = false, tile_path = false, tile_force_only = false;
+  int ntile2 = 0, ntile3 = 0;
   double lane_redundancy = 1.0;
   fa::launch_fn launch = nullptr;
   fa::Params P{};
@@ -263,6 +264,8 @@ struct fa_ctx {
   int32_t* d_conn = nullptr; double* d_coords = nullptr; int64_t* d_row_ptr = nullptr; int32_t* d_col_idx = nullptr;
   int64_t* d_node_dofs = nullptr; int32_t* d_n2e_ptr = nullptr; int32_t* d_n2e_ent = nullptr; uint8_t* d_pos = nullptr;
   int32_t* d_wg_start = nullptr; double* d_tab = nullptr; int32_t* d_lrec = nullptr; int32_t* d_wginfo = nullptr; int32_t* d_lrec2 = nullptr; int32_t* d_wginfo2 = nullptr;
+  int32_t *d_tinfo = nullptr, *d_tnodes = nullptr, *d_telems = nullptr; uint16_t* d_tconn = nullptr;
+  uint32_t *d_tpairs = nullptr, *d_tents = nullptr;
   int32_t *d_pn_ptr = nullptr, *d_pe_ptr = nullptr, *d_pr_ptr = nullptr, *d_pnode = nullptr, *d_poff = nullptr,
           *d_prec = nullptr, *d_prun = nullptr;
   double* d_hist[2] = { nullptr, nullptr };   // [0] preHist_, [1] newHist_
@@ -280,7 +283,8 @@ extern "C" void fa_destroy(fa_ctx* c) {
   void* ptrs[] = { c->d_conn, c->d_coords, c->d_row_ptr, c->d_col_idx, c->d_node_dofs, c->d_n2e_ptr, c->d_n2e_ent,
                    c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part,
                    c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err,
-                   c->d_pn_ptr, c->d_pe_ptr, c->d_pr_ptr, c->d_pnode, c->d_poff, c->d_prec, c->d_prun };
+                   c->d_pn_ptr, c->d_pe_ptr, c->d_pr_ptr, c->d_pnode, c->d_poff, c->d_prec, c->d_prun,
+                   c->d_tinfo, c->d_tnodes, c->d_telems, c->d_tconn, c->d_tpairs, c->d_tents };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete c;
 }
@@ -643,6 +647,32 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
               "Gauss-point redundancy %.3f\n", ps.npatch, (double)nnode / ps.npatch, (double)ps.nrec / ps.npatch,
               (double)ps.prun.size() / ps.npatch, ps.max_lds, ps.lane_redundancy);
   }
+  // ---- node tiles (tile kernel: GET_MATRIX0 passes of the 3-D shapes) ----
+  fa::TileSet ts;
+  {
+    // default: the higher-order shapes (they have no row kernel) and Hex8 with an isotropic-form tangent (the
+    // general-tangent records are too large for a good Hex8 tile: the row kernel stays faster there).
+    // FA_TILES=0 / 1 turns the tile kernel off / on for every shape (experiments).
+    const char* env = getenv("FA_TILES");
+    const bool wanted = env ? (atoi(env) != 0) : (c->coop || (p->shape == FA_HEX8_G2 && c->fam != fa::FAM_PF_MIEHE));
+
+    if (P.canon && wanted && nel > 0) {
+      const bool keepK = P.keep2 || P.keep3;
+      const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE;
+      c->tile_path = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
+                                     nb_ptr.data(), nb.data(), fa::tile_rec_doubles(rank, c->fam, keepK),
+                                     fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0), fa::kTileLds, ts);
+      if (c->tile_path) { c->ntile3 = ts.ntile; P.ntile3 = ts.ntile; P.tile_lds = ts.lds_bytes; }
+      // GET_INT_VECTOR passes keep no records, so a tile set sized for GET_MATRIX0 pays its Gauss-point redundancy for
+      // nothing: measured faster than the row / cooperative kernels up to ~3 evaluations per point (Hex20 Gauss3: 5)
+      c->tile_force_only = c->tile_path && (env ? true : ts.point_redundancy < 3.0);
+      if (getenv("FA_VERBOSE"))
+        fprintf(stderr, "[falcon_assemble] tiles: %s, %d tiles, %.1f owned nodes / %.1f elements per tile, LDS <= %d bytes, "
+                "Gauss-point redundancy %.3f\n", c->tile_path ? "ok" : "not built", ts.ntile,
+                ts.ntile ? (double)nnode / ts.ntile : 0.0, ts.ntile ? (double)ts.telems.size() / ts.ntile : 0.0,
+                ts.lds_bytes, ts.point_redundancy);
+    }
+  }
   c->nwg = rows_ok ? (int)wg_start.size() - 1 : 0;
   c->ngrid_generic = (int)((nel * npe + kBlock - 1) / kBlock);
 
@@ -682,6 +712,14 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     tab.insert(tab.end(), sh.w.begin(), sh.w.end());
     if ((st = upload(&c->d_tab, tab.data(), tab.size()))) return st;
   }
+  if (c->tile_path) {
+    if ((st = upload(&c->d_tinfo, ts.tinfo.data(), ts.tinfo.size()))) return st;
+    if ((st = upload(&c->d_tnodes, ts.tnodes.data(), ts.tnodes.size()))) return st;
+    if ((st = upload(&c->d_telems, ts.telems.data(), ts.telems.size()))) return st;
+    if ((st = upload(&c->d_tconn, ts.tconn.data(), ts.tconn.size()))) return st;
+    if ((st = upload(&c->d_tpairs, ts.tpairs.data(), ts.tpairs.size()))) return st;
+    if ((st = upload(&c->d_tents, ts.tents.data(), std::max<size_t>(ts.tents.size(), 1)))) return st;
+  }
   const int64_t nipt = nel * sh.nip;
   if (p->model == FA_PHASE_FRACTURE || p->model >= FA_MICRO_PHASE_FRACTURE) {
     for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void**)&c->d_hist[k], std::max<int64_t>(nipt, 1) * sizeof(double)));
@@ -690,12 +728,13 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[1], nipt, 0.0);
   }
   if (p->model == FA_PHASE_FRACTURE_EXTIT || p->model == FA_MICRO_PHASE_FRACTURE_EXTIT)
-    HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(std::max(std::max(std::max(c->nwg, c->ntile2), c->ngrid_generic), c->npatch), c->ngrid_coop)));
+    HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(std::max(std::max(std::max(std::max(c->nwg, c->ntile2), c->ngrid_generic), c->npatch), c->ngrid_coop), c->ntile3)));
   HIP_TRY(hipDeviceSynchronize());
 
   P.conn = c->d_conn; P.coords = c->d_coords; P.row_ptr = c->d_row_ptr; P.col_idx = c->d_col_idx;
   P.node_dofs = c->d_node_dofs; P.n2e_ptr = c->d_n2e_ptr; P.n2e_ent = c->d_n2e_ent; P.pos = c->d_pos;
   P.wg_start = c->d_wg_start; P.lrec = c->d_lrec; P.wginfo = c->d_wginfo; P.lrec2 = c->d_lrec2; P.wginfo2 = c->d_wginfo2; P.ntile2 = c->ntile2; P.tab = c->d_tab; P.max_valence = c->max_valence;
+  P.tinfo = c->d_tinfo; P.tnodes = c->d_tnodes; P.telems = c->d_telems; P.tconn = c->d_tconn; P.tpairs = c->d_tpairs; P.tents = c->d_tents;
   P.pn_ptr = c->d_pn_ptr; P.pe_ptr = c->d_pe_ptr; P.pr_ptr = c->d_pr_ptr; P.pnode = c->d_pnode; P.poff = c->d_poff;
   P.prec = c->d_prec; P.prun = c->d_prun; P.plds = c->plds;
   return FA_OK;
@@ -780,6 +819,7 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   int path = c->coop ? fa::PATH_COOP : fa::PATH_GENERIC;
   if (c->rows_path && !(a->flags & FA_FORCE_GENERIC))
     path = (a->flags & FA_DETERMINISTIC) ? fa::PATH_ROWS_ORDERED : (c->patch_path ? fa::PATH_PATCH : (c->pair_path ? fa::PATH_ROWS_PAIR : fa::PATH_ROWS));
+  if (c->tile_path && (want_K || c->tile_force_only) && !(a->flags & (FA_FORCE_GENERIC | FA_DETERMINISTIC))) path = fa::PATH_TILES;
   if (c->nel == 0) {
     if (P.overwrite) {
       if (want_K) HIP_TRY(hipMemsetAsync(a->K_values, 0, sizeof(double) * c->nnz, st));
@@ -792,6 +832,7 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   if (path == fa::PATH_PATCH) grid = c->npatch;
   else if (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) { P.ntile = c->nwg; grid = (c->nwg + 7) / 8 * 8; }
   else if (path == fa::PATH_ROWS_PAIR) grid = (c->ntile2 + 7) / 8 * 8;
+  else if (path == fa::PATH_TILES) grid = (c->ntile3 + 7) / 8 * 8;
   else {
     grid = c->coop ? c->ngrid_coop : c->ngrid_generic;
     if (a->flags & FA_FORCE_GENERIC) P.canon = 0;      // testing: per-entry column search
@@ -819,7 +860,7 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   if (rc == -1000) return fail(FA_ERR_UNSUPPORTED, "kernel family not built for this shape");
   if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   if (want_err) {
-    const int nparts = (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) ? c->nwg : (path == fa::PATH_ROWS_PAIR ? c->ntile2 : grid);
+    const int nparts = (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) ? c->nwg : (path == fa::PATH_ROWS_PAIR ? c->ntile2 : (path == fa::PATH_TILES ? c->ntile3 : grid));
     hipLaunchKernelGGL(reduce_err_kernel, dim3(1), dim3(256), 0, st, c->d_err_part, nparts, a->err_ext);
     HIP_TRY(hipGetLastError());
   }

@@ -1,5 +1,6 @@
 // fa_internal.h -- shared between the host-side C ABI (fa_api.cpp) and the gfx950 kernels.
 #pragma once
+#include <cstddef>
 #include <stdint.h>
 
 namespace fa {
@@ -40,7 +41,32 @@ constexpr int lrec_stride(int npe) { return ((2 + npe + (npe + 3) / 4) + 3) / 4 
 constexpr int lrec_stride2(int npe) { return ((3 + npe + (npe + 3) / 4) + 3) / 4 * 4; }
 // per workgroup: n0, n1, first lane t0 (lo), lane count, CSR base (lo, hi), image length, t0 (hi)
 constexpr int kWgInfo = 8;
-enum { PATH_PATCH = 0, PATH_ROWS = 1, PATH_GENERIC = 2, PATH_ROWS_ORDERED = 3, PATH_COOP = 4, PATH_ROWS_PAIR = 5 };
+enum { PATH_PATCH = 0, PATH_ROWS = 1, PATH_GENERIC = 2, PATH_ROWS_ORDERED = 3, PATH_COOP = 4, PATH_ROWS_PAIR = 5, PATH_TILES = 6 };
+
+// kernel family: which compute core is instantiated
+enum { FAM_LE = 0, FAM_PF_ISO = 1, FAM_PF_MIEHE = 2 };
+
+// tile kernel (fa_tile_impl.h): workgroup size, LDS budget of one tile, descriptor words per tile
+// (node offset, nodes, owned nodes, element offset, elements, pair offset, pairs, entry offset)
+#ifndef FA_TILE_BLOCK
+#define FA_TILE_BLOCK 512
+#endif
+#ifndef FA_TILE_LDS
+#define FA_TILE_LDS 81856
+#endif
+constexpr int kTileBlock = FA_TILE_BLOCK, kTileLds = FA_TILE_LDS, kTileInfo = 8;
+// doubles of one Gauss-point record: J^-1, w det J, tangent (3 isotropic coefficients or the packed symmetric D),
+// c1 for phase-field families, sigma+ / g' / loading g' when the off-diagonal blocks are kept
+constexpr int tile_rec_doubles(int rank, int fam, bool keep) {
+  const int S = (rank == 2) ? 3 : 6;
+  return rank * rank + 1 + (fam == FAM_PF_MIEHE ? S * (S + 1) / 2 : 3) + (fam != FAM_LE ? 1 : 0) + (keep ? S + 2 : 0);
+}
+// doubles of one element slot (nip records): odd, so that lanes reading the same field of different slots spread
+// over the LDS banks
+constexpr int tile_slot_doubles(int nip, int rec_doubles) { return (nip * rec_doubles) | 1; }
+// doubles staged per tile node: x, u and (phase-field families) phi; the Ext variants add phi of state0 and of
+// state00 / stateExt_ in an array of their own
+constexpr int tile_node_doubles(int rank, bool pf) { return 2 * rank + (pf ? 1 : 0); }
 
 // cooperative element kernel (higher-order shapes): elements per workgroup so that the LDS slots of the largest
 // family (Miehe with off-diagonal blocks) stay below 64 KB
@@ -52,9 +78,6 @@ constexpr int coop_epb(int rank, int npe, int nip) {
   const int n = 8000 / coop_slot_doubles(rank, npe, nip);
   return n < 1 ? 1 : (n > 32 ? 32 : n);
 }
-
-// kernel family: which compute core is instantiated
-enum { FAM_LE = 0, FAM_PF_ISO = 1, FAM_PF_MIEHE = 2 };
 
 struct Params {
   // ---- mesh / topology (device) ----
@@ -80,6 +103,13 @@ struct Params {
   const int32_t* poff;       // nnode+npatch  LDS offset of every owned node's row block, +1 sentinel per patch
   const int32_t* prec;       // per patch element: record of prec_stride(npe) words (see above)
   const int32_t* prun;       // first owned index | count << 16
+  // tile kernel: compact node tiles with their halo of elements (fa_tile_impl.h)
+  const int32_t*  tinfo;     // ntile3 * kTileInfo
+  const int32_t*  tnodes;    // tile nodes, owned ones first
+  const int32_t*  telems;    // tile elements, ascending; bit 31: this tile stores the element's per-point outputs
+  const uint16_t* tconn;     // per tile element: npe indices into the tile's node list
+  const uint32_t* tpairs;    // per (owned node, neighbour): owned index | position in the row << 16 | elements << 24, entry offset
+  const uint32_t* tents;     // per (pair, shared element): slot | local node a << 16 | local node b << 24
   const double*  tab;        // shape tables: N[nip][npe], dN[nip][npe][rank], w[nip]
   // ---- vectors (device) ----
   const double*  state;
@@ -94,7 +124,7 @@ struct Params {
   double*        f;
   // ---- sizes / switches ----
   int64_t nnode, nel;
-  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2;
+  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2, ntile3, tile_lds;
   int32_t cnt[4];            // entries per neighbour node in a row of dof type i
   int32_t off[4][4];         // offset of column type j inside that group, -1 if not in the pattern
   // ---- constants ----

@@ -1,0 +1,437 @@
+// fa_tile_impl.h -- tile kernel for the 3-D and higher-order shapes (GET_MATRIX0 passes).
+//
+// A tile is a compact set of owned nodes (a block of the spatially sorted node sequence, built in fa_api.hip)
+// together with every element that touches one of them.  One workgroup per tile:
+//   phase 0  stage    nodal coordinates / state of the tile's nodes, the shape tables and the local connectivity
+//                     go to LDS
+//   phase 1  points   one lane per (element, Gauss point): Jacobian, B u, degradation, material update, history
+//                     (PhaseFractureModel.cpp:629-703).  The point leaves a short record in LDS -- J^-1, w det J and
+//                     the constitutive coefficients -- and adds its f_int contributions for the owned nodes to an
+//                     LDS image of the tile's f rows.  Each point of an element is evaluated once per tile that
+//                     touches the element (1.5-2.5 times per pass instead of NPE times in the row kernel).
+//   phase 2  pairs    one lane per (owned node a, neighbour b): the (rank+1)^2 block of K1..K4 summed over the
+//                     elements that hold both nodes and over their Gauss points (:713-722), read from the LDS
+//                     records, and written straight to its CSR entries.  Every entry of K has exactly one writer:
+//                     no atomics, no LDS image of the rows, deterministic summation order (element-ascending).
+// Lanes of phase 2 are sorted by their element count (8/4/2/1 for a structured Hex8 mesh) so that a wave does
+// uniform work.  Registers stay low (16 accumulators), which is what the row kernel cannot offer in 3-D, where
+// its 4 x 32 row block pins it at one wave per SIMD.
+#pragma once
+#include "fa_kernel_impl.h"
+
+#ifndef FA_TILE_UNROLL_A
+#define FA_TILE_UNROLL_A 1
+#endif
+#ifndef FA_TILE_UNROLL_IP
+#define FA_TILE_UNROLL_IP 1
+#endif
+
+namespace fa {
+
+template <class SH, int FAM, bool KEEP>
+struct TileRec {                                        // offsets (doubles) inside one Gauss-point record
+  static constexpr int R = SH::RANK, S = SH::S;
+  static constexpr bool PF = (FAM != FAM_LE), GEN = (FAM == FAM_PF_MIEHE);
+  static constexpr int O_INV = 0, O_W = R * R, O_D = O_W + 1, NDC = GEN ? S * (S + 1) / 2 : 3;
+  static constexpr int O_C1 = O_D + NDC, O_SP = O_C1 + (PF ? 1 : 0), W = O_SP + (KEEP ? S + 2 : 0);
+  static_assert(W == tile_rec_doubles(R, FAM, KEEP), "host and device disagree on the record width");
+};
+
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP>
+__global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
+  constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, S = SH::S, STR = SH::STR, BLK = kTileBlock;
+  constexpr bool PF = (FAM != FAM_LE);
+  constexpr int NDOF = PF ? RANK + 1 : RANK;
+  using TR = TileRec<SH, FAM, KEEP>;
+  constexpr int RW = TR::W, SLOTW = tile_slot_doubles(NIP, RW), NODW = tile_node_doubles(RANK, PF);
+  constexpr int TABN = NIP * NPE * (1 + RANK) + NIP;
+  extern __shared__ double smem[];
+  __shared__ double sErr[BLK / 64];
+
+  const int tid = threadIdx.x;
+  const int per = (int)gridDim.x >> 3;                 // XCD bands: neighbouring tiles share halo nodes in one L2
+  const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (tile >= P.ntile3) return;
+  const int32_t* __restrict__ ti = P.tinfo + (int64_t)tile * kTileInfo;
+  const int node_off = ti[0], n_all = ti[1], n_own = ti[2], elem_off = ti[3], n_el = ti[4];
+  const int pair_off = ti[5], n_pairs = ti[6], ent_off = ti[7];
+
+  double* sRec = smem;
+  double* sNod = sRec + (WANT_K ? n_el * SLOTW : 0);   // GET_INT_VECTOR passes keep no records
+  double* sExt = sNod + n_all * NODW;                 // phi of state0 / state00 (stateExt_), Ext variants only
+  const bool ext_state = PF && (SP::model(P) == 2 || SP::model(P) == 3 || SP::model(P) >= 5);
+  double* sF   = sExt + (ext_state ? 2 * n_all : 0);
+  double* sTab = sF + n_own * NDOF;
+  uint16_t* sConn = (uint16_t*)(sTab + TABN);
+  const double* tabN = sTab;
+  const double* tabD = sTab + NIP * NPE;
+  const double* tabW = sTab + NIP * NPE * (1 + RANK);
+
+  // ---- phase 0: stage ----
+  for (int i = tid; i < n_all; i += BLK) {
+    const int64_t n = P.tnodes[node_off + i];
+    double* nd = sNod + i * NODW;
+#pragma unroll
+    for (int d = 0; d < RANK; d++) { nd[d] = P.coords[n * RANK + d]; nd[RANK + d] = P.state[n * NDOF + d]; }
+    if constexpr (PF) {
+      const int64_t dp = n * NDOF + RANK;
+      nd[2 * RANK] = P.state[dp];
+      if (SP::model(P) == 2 || SP::model(P) == 3) { sExt[2 * i] = P.state0[dp]; sExt[2 * i + 1] = P.stateX[dp]; }
+      else if (SP::model(P) >= 5) { sExt[2 * i] = 0.0; sExt[2 * i + 1] = P.stateX[dp]; }
+    }
+  }
+  for (int i = tid; i < n_own * NDOF; i += BLK) sF[i] = 0.0;
+  for (int i = tid; i < TABN; i += BLK) sTab[i] = P.tab[i];
+  for (int i = tid; i < n_el * NPE; i += BLK) sConn[i] = P.tconn[(int64_t)elem_off * NPE + i];
+  __syncthreads();
+
+  // ---- phase 1: Gauss points ----
+  double err_acc = 0.0;
+  for (int t = tid; t < n_el * NIP; t += BLK) {
+    const int s = t / NIP, ip = t - s * NIP;
+    const uint32_t ew = (uint32_t)P.telems[elem_off + s];
+    const int64_t e = (int64_t)(ew & 0x7FFFFFFFu);
+    const bool write = (ew >> 31) != 0;                // this tile stores the element's history / strain / errExt_
+    const uint16_t* lc = sConn + s * NPE;
+    double J[RANK][RANK];
+#pragma unroll
+    for (int i = 0; i < RANK; i++)
+#pragma unroll
+      for (int k = 0; k < RANK; k++) J[i][k] = 0.0;
+#pragma unroll FA_TILE_UNROLL_A
+    for (int a = 0; a < NPE; a++) {
+      const double* nd = sNod + (int)lc[a] * NODW;
+#pragma unroll
+      for (int k = 0; k < RANK; k++) {
+        const double dn = tabD[(ip * NPE + a) * RANK + k];
+#pragma unroll
+        for (int i = 0; i < RANK; i++) J[i][k] += nd[i] * dn;
+      }
+    }
+    double inv[RANK][RANK], det;
+    if constexpr (RANK == 2) {
+      det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+      const double rd = 1.0 / det;
+      inv[0][0] = J[1][1] * rd;  inv[0][1] = -J[0][1] * rd;
+      inv[1][0] = -J[1][0] * rd; inv[1][1] = J[0][0] * rd;
+    } else {
+      const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+      const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+      const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+      det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+      const double rd = 1.0 / det;
+      inv[0][0] = c00 * rd;
+      inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
+      inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * rd;
+      inv[1][0] = c01 * rd;
+      inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * rd;
+      inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rd;
+      inv[2][0] = c02 * rd;
+      inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
+      inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
+    }
+    const double w = tabW[ip] * det;
+    double eps[S], pf = 0.0, pf0 = 0.0, pfX = 0.0, gphi[RANK];
+#pragma unroll
+    for (int c = 0; c < S; c++) eps[c] = 0.0;
+#pragma unroll
+    for (int i = 0; i < RANK; i++) gphi[i] = 0.0;
+#pragma unroll FA_TILE_UNROLL_A
+    for (int a = 0; a < NPE; a++) {
+      const double* nd = sNod + (int)lc[a] * NODW;
+      double ga[RANK], ua[RANK];
+#pragma unroll
+      for (int i = 0; i < RANK; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < RANK; k++) acc += tabD[(ip * NPE + a) * RANK + k] * inv[k][i];
+        ga[i] = acc; ua[i] = nd[RANK + i];
+      }
+      if constexpr (RANK == 2) {                       // strain = B u (ShapeUtils.cpp:73-104)
+        eps[0] += ga[0] * ua[0]; eps[1] += ga[1] * ua[1];
+        eps[2] += ga[1] * ua[0]; eps[2] += ga[0] * ua[1];
+      } else {                                         // ShapeUtils.cpp:114-145
+        eps[0] += ga[0] * ua[0]; eps[1] += ga[1] * ua[1]; eps[2] += ga[2] * ua[2];
+        eps[3] += ga[1] * ua[0]; eps[3] += ga[0] * ua[1];
+        eps[4] += ga[2] * ua[1]; eps[4] += ga[1] * ua[2];
+        eps[5] += ga[0] * ua[2]; eps[5] += ga[2] * ua[0];
+      }
+      if constexpr (PF) {
+        const double Na = tabN[ip * NPE + a], ph = nd[2 * RANK];
+        pf += Na * ph;
+#pragma unroll
+        for (int i = 0; i < RANK; i++) gphi[i] += ga[i] * ph;
+        if (SP::model(P) == 2 || SP::model(P) == 3) { pf0 += Na * sExt[2 * (int)lc[a]]; pfX += Na * sExt[2 * (int)lc[a] + 1]; }
+        else if (SP::model(P) >= 5) pfX += Na * sExt[2 * (int)lc[a] + 1];
+      }
+    }
+    const int64_t ipoint = e * NIP + ip;               // initializeIPMPMap_, PhaseFractureModel.cpp:1070-1093
+    if (P.strain != nullptr && write) {
+      double* sc = P.strain + ipoint * (PF ? STR + 1 : STR);
+      if constexpr (RANK == 2) { sc[0] = eps[0]; sc[1] = eps[1]; sc[2] = 0.0; sc[3] = eps[2]; }
+      else {
+#pragma unroll
+        for (int c = 0; c < S; c++) sc[c] = eps[c];
+      }
+    }
+    double H0 = 0.0;
+    if constexpr (PF) {
+      if (SP::model(P) == 1 || SP::model(P) >= 4) H0 = P.hist_pre[ipoint];
+    }
+    IpMat<SH, FAM, KEEP> m;
+    ip_material<SH, FAM, KEEP, SP>(P, ipoint, eps, pf, pf0, pfX, H0, write, m, err_acc);
+
+    if constexpr (WANT_K) {
+    double* rec = sRec + s * SLOTW + ip * RW;
+#pragma unroll
+    for (int k = 0; k < RANK; k++)
+#pragma unroll
+      for (int i = 0; i < RANK; i++) rec[TR::O_INV + k * RANK + i] = inv[k][i];
+    rec[TR::O_W] = w;
+    if constexpr (FAM == FAM_PF_MIEHE) {
+      int q = 0;
+#pragma unroll
+      for (int i = 0; i < S; i++)
+#pragma unroll
+        for (int j = i; j < S; j++) rec[TR::O_D + (q++)] = m.D[i][j];
+    } else {
+      rec[TR::O_D] = m.d0; rec[TR::O_D + 1] = m.d1; rec[TR::O_D + 2] = m.d3;
+    }
+    if constexpr (PF) rec[TR::O_C1] = m.c1;
+    if constexpr (KEEP) {
+#pragma unroll
+      for (int c = 0; c < S; c++) rec[TR::O_SP + c] = m.sp[c];
+      rec[TR::O_SP + S] = m.dg; rec[TR::O_SP + S + 1] = m.dgl;
+    }
+    }
+
+    // f1 += w B^T sigma, f2 (PhaseFractureModel.cpp:727-730) for the owned nodes.  The node loop starts at a
+    // different node in every lane of an element so that its lanes do not add to one address at the same time.
+#pragma unroll 1
+    for (int q = 0; q < NPE; q++) {
+      int a = q + (ip % NPE); if (a >= NPE) a -= NPE;
+      const int li = (int)lc[a];
+      if (li >= n_own) continue;
+      double wga[RANK], tt[RANK];
+#pragma unroll
+      for (int i = 0; i < RANK; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < RANK; k++) acc += tabD[(ip * NPE + a) * RANK + k] * inv[k][i];
+        wga[i] = w * acc;
+      }
+      Bt_vec<RANK, S>(wga, m.sig, tt);
+#pragma unroll
+      for (int i = 0; i < RANK; i++) atomicAdd(&sF[li * NDOF + i], tt[i]);
+      if constexpr (PF) {
+        double gg = 0.0;
+#pragma unroll
+        for (int i = 0; i < RANK; i++) gg += wga[i] * gphi[i];
+        atomicAdd(&sF[li * NDOF + RANK], (w * tabN[ip * NPE + a]) * m.cf + P.c2 * gg);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- f_int rows of the owned nodes ----
+  for (int i = tid; i < n_own * NDOF; i += BLK) {
+    const int ia = i / NDOF;
+    const int64_t q = (int64_t)P.tnodes[node_off + ia] * NDOF + (i - ia * NDOF);
+    P.f[q] = P.overwrite ? sF[i] : P.f[q] + sF[i];
+  }
+
+  // ---- phase 2: node-pair blocks of K1..K4 (PhaseFractureModel.cpp:713-722) ----
+  if constexpr (WANT_K) {
+#ifdef FA_TILE_TAB_GLOBAL                              // shape tables through the vector-memory pipe (L1 hits), records from LDS
+  const double* __restrict__ tab2N = P.tab;
+  const double* __restrict__ tab2D = P.tab + NIP * NPE;
+#else
+  const double* tab2N = tabN;
+  const double* tab2D = tabD;
+#endif
+  for (int p = tid; p < n_pairs; p += BLK) {
+    const uint32_t w0 = P.tpairs[((int64_t)pair_off + p) * 2], w1 = P.tpairs[((int64_t)pair_off + p) * 2 + 1];
+    const int ia = (int)(w0 & 0xFFFFu), kpos = (int)((w0 >> 16) & 0xFFu), cnt = (int)(w0 >> 24);
+    const uint32_t* __restrict__ ents = P.tents + (int64_t)ent_off + w1;
+    double Kuu[RANK][RANK], Kpp = 0.0, Kup[RANK], Kpu[RANK];
+#pragma unroll
+    for (int i = 0; i < RANK; i++) {
+      Kup[i] = 0.0; Kpu[i] = 0.0;
+#pragma unroll
+      for (int j = 0; j < RANK; j++) Kuu[i][j] = 0.0;
+    }
+    uint32_t ent_next = (cnt > 0) ? ents[0] : 0u;
+#pragma unroll 1
+    for (int t = 0; t < cnt; t++) {
+      const uint32_t ent = ent_next;
+      if (t + 1 < cnt) ent_next = ents[t + 1];          // in flight while this element's points are summed
+      const int slot = (int)(ent & 0xFFFFu), la = (int)((ent >> 16) & 0xFFu), lb = (int)(ent >> 24);
+#pragma unroll FA_TILE_UNROLL_IP
+      for (int ip = 0; ip < NIP; ip++) {
+        const double* rec = sRec + slot * SLOTW + ip * RW;
+        const double w = rec[TR::O_W];
+        double wga[RANK], gb[RANK];
+#pragma unroll
+        for (int i = 0; i < RANK; i++) {               // same expression as phase 1: the gradients are bit-identical
+          double acca = 0.0, accb = 0.0;
+#pragma unroll
+          for (int k = 0; k < RANK; k++) {
+            acca += tab2D[(ip * NPE + la) * RANK + k] * rec[TR::O_INV + k * RANK + i];
+            accb += tab2D[(ip * NPE + lb) * RANK + k] * rec[TR::O_INV + k * RANK + i];
+          }
+          wga[i] = w * acca; gb[i] = accb;
+        }
+        if constexpr (FAM == FAM_PF_MIEHE) {
+          double D[S][S];
+          {
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < S; i++)
+#pragma unroll
+              for (int j = i; j < S; j++) { const double v = rec[TR::O_D + q]; q++; D[i][j] = v; D[j][i] = v; }
+          }
+#pragma unroll
+          for (int i = 0; i < RANK; i++) {             // row i of w B_a^T D, then (.) B_b
+            double Bi[S], row[S], tt[RANK];
+#pragma unroll
+            for (int c = 0; c < S; c++) Bi[c] = 0.0;
+            if constexpr (RANK == 2) { if (i == 0) { Bi[0] = wga[0]; Bi[2] = wga[1]; } else { Bi[1] = wga[1]; Bi[2] = wga[0]; } }
+            else {
+              if (i == 0) { Bi[0] = wga[0]; Bi[3] = wga[1]; Bi[5] = wga[2]; }
+              else if (i == 1) { Bi[1] = wga[1]; Bi[3] = wga[0]; Bi[4] = wga[2]; }
+              else { Bi[2] = wga[2]; Bi[4] = wga[1]; Bi[5] = wga[0]; }
+            }
+#pragma unroll
+            for (int c = 0; c < S; c++) {
+              double acc = 0.0;
+#pragma unroll
+              for (int k = 0; k < S; k++) acc += Bi[k] * D[k][c];
+              row[c] = acc;
+            }
+            Bt_vec<RANK, S>(gb, row, tt);
+#pragma unroll
+            for (int j = 0; j < RANK; j++) Kuu[i][j] += tt[j];
+          }
+        } else if constexpr (RANK == 2) {
+          const double d0 = rec[TR::O_D], d1 = rec[TR::O_D + 1], d3 = rec[TR::O_D + 2];
+          Kuu[0][0] += (wga[0] * d0) * gb[0] + (wga[1] * d3) * gb[1];
+          Kuu[0][1] += (wga[0] * d1) * gb[1] + (wga[1] * d3) * gb[0];
+          Kuu[1][0] += (wga[1] * d1) * gb[0] + (wga[0] * d3) * gb[1];
+          Kuu[1][1] += (wga[1] * d0) * gb[1] + (wga[0] * d3) * gb[0];
+        } else {
+          const double d0 = rec[TR::O_D], d1 = rec[TR::O_D + 1], d3 = rec[TR::O_D + 2];
+          const double dotp = wga[0] * gb[0] + wga[1] * gb[1] + wga[2] * gb[2];
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+              if (i == j) Kuu[i][j] += (d0 - d3) * (wga[i] * gb[i]) + d3 * dotp;
+              else        Kuu[i][j] += d1 * (wga[i] * gb[j]) + d3 * (wga[j] * gb[i]);
+            }
+        }
+        if constexpr (PF) {
+          const double Na = tab2N[ip * NPE + la], Nb = tab2N[ip * NPE + lb];
+          const double wNa = w * Na;
+          double gab = 0.0;
+#pragma unroll
+          for (int i = 0; i < RANK; i++) gab += wga[i] * gb[i];
+          Kpp += (wNa * rec[TR::O_C1]) * Nb + P.c2 * gab;               // K4 (:714-716)
+          if constexpr (KEEP) {
+            double spv[S], tt[RANK];
+#pragma unroll
+            for (int c = 0; c < S; c++) spv[c] = rec[TR::O_SP + c];
+            if (P.keep2) {                                              // K2 (:720)
+              Bt_vec<RANK, S>(wga, spv, tt);
+              const double dg = rec[TR::O_SP + S];
+#pragma unroll
+              for (int i = 0; i < RANK; i++) Kup[i] += (dg * tt[i]) * Nb;
+            }
+            if (P.keep3) {                                              // K3 (:721)
+              Bt_vec<RANK, S>(gb, spv, tt);
+              const double dgl = rec[TR::O_SP + S + 1];
+#pragma unroll
+              for (int j = 0; j < RANK; j++) Kpu[j] += (wNa * dgl) * tt[j];
+            }
+          }
+        }
+      }
+    }
+    // ---- the block's CSR entries: rows of node a, columns of its kpos-th neighbour (canonical blocked layout) ----
+    const int64_t na = P.tnodes[node_off + ia];
+    auto put = [&](int i, int j, double v) {
+      const int o = P.off[i][j];
+      if (o < 0) return;
+      const int64_t q = P.row_ptr[na * NDOF + i] + (int64_t)kpos * P.cnt[i] + o;
+      P.K[q] = P.overwrite ? v : P.K[q] + v;
+    };
+    if (NDOF == 4 && P.cnt[0] == 4 && P.cnt[3] == 4) {   // full 4x4 block: each row chunk is 32 bytes, 32-byte aligned
+      if constexpr (NDOF == 4) {
+        double blk[4][4];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+          for (int j = 0; j < 3; j++) blk[i][j] = Kuu[i][j];
+          blk[i][3] = (KEEP && P.keep2) ? Kup[i] : 0.0;
+          blk[3][i] = (KEEP && P.keep3) ? Kpu[i] : 0.0;
+        }
+        blk[3][3] = Kpp;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          double2* q = reinterpret_cast<double2*>(P.K + P.row_ptr[na * 4 + i] + (int64_t)kpos * 4);
+          double2 v0 = make_double2(blk[i][0], blk[i][1]), v1 = make_double2(blk[i][2], blk[i][3]);
+          if (!P.overwrite) { const double2 o0 = q[0], o1 = q[1]; v0.x += o0.x; v0.y += o0.y; v1.x += o1.x; v1.y += o1.y; }
+          q[0] = v0; q[1] = v1;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < RANK; i++) {
+#pragma unroll
+        for (int j = 0; j < RANK; j++) put(i, j, Kuu[i][j]);
+        if constexpr (PF) put(i, RANK, (KEEP && P.keep2) ? Kup[i] : 0.0);
+      }
+      if constexpr (PF) {
+#pragma unroll
+        for (int j = 0; j < RANK; j++) put(RANK, j, (KEEP && P.keep3) ? Kpu[j] : 0.0);
+        put(RANK, RANK, Kpp);
+      }
+    }
+  }
+  }
+  if (PF && P.err_part != nullptr) reduce_err<BLK>(err_acc, sErr, &P.err_part[tile]);
+}
+
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP>
+static int launch_tiles_one(const Params& P, int grid, hipStream_t st) {
+  auto kern = assemble_tiles<SH, FAM, WANT_K, KEEP, SP>;
+  static size_t configured = 0;                        // per instantiation
+  const size_t shmem = (size_t)P.tile_lds;
+  if (shmem > 65536 - 64 && shmem > configured) {
+    hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (rc != hipSuccess) return (int)rc;
+    configured = shmem;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kTileBlock), shmem, st, P);
+  return (int)hipGetLastError();
+}
+
+template <class SH>
+static int launch_tiles_shape(const Params& P, int fam, bool want_K, bool keep, int grid, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (fam == FAM_LE)
+    return want_K ? launch_tiles_one<SH, FAM_LE, true, false, SpecFixed<0, 0, 0>>(P, grid, st)
+                  : launch_tiles_one<SH, FAM_LE, false, false, SpecFixed<0, 0, 0>>(P, grid, st);
+  if (fam == FAM_PF_ISO) {
+    if (!want_K) return launch_tiles_one<SH, FAM_PF_ISO, false, false, SpecCanon>(P, grid, st);
+    return keep ? launch_tiles_one<SH, FAM_PF_ISO, true, true, SpecCanon>(P, grid, st)
+                : launch_tiles_one<SH, FAM_PF_ISO, true, false, SpecCanon>(P, grid, st);
+  }
+  if (fam == FAM_PF_MIEHE) {
+    if (!want_K) return launch_tiles_one<SH, FAM_PF_MIEHE, false, false, SpecCanon>(P, grid, st);
+    return keep ? launch_tiles_one<SH, FAM_PF_MIEHE, true, true, SpecCanon>(P, grid, st)
+                : launch_tiles_one<SH, FAM_PF_MIEHE, true, false, SpecCanon>(P, grid, st);
+  }
+  return -1000;
+}
+
+}  // namespace fa

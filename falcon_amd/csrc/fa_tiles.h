@@ -1,0 +1,29 @@
+// fa_tiles.h -- host-side construction of the node tiles of the tile kernel (fa_tile_impl.h).
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+namespace fa {
+
+struct TileSet {
+  int ntile = 0;
+  int lds_bytes = 0;                     // largest LDS footprint of a tile (dynamic shared memory of the launch)
+  std::vector<int32_t> tinfo;            // kTileInfo words per tile
+  std::vector<int32_t> tnodes;           // nodes of every tile, owned ones first
+  std::vector<int32_t> telems;           // elements of every tile, ascending; bit 31 = tile stores the per-point outputs
+  std::vector<uint16_t> tconn;           // npe local node indices per tile element
+  std::vector<uint32_t> tpairs;          // 2 words per (owned node, neighbour), sorted by element count inside a tile
+  std::vector<uint32_t> tents;           // one word per (pair, shared element)
+  double point_redundancy = 0.0;         // tile elements / elements: how often a Gauss point is evaluated per pass
+};
+
+// Nodes are sorted along a Morton curve of their grid-quantised coordinates and cut into tiles whose staged data
+// (Gauss-point records of `rec_doubles` each, `node_doubles` per node, f image, shape tables, local connectivity)
+// fit `lds_budget` bytes.  nb_ptr / nb: sorted neighbour lists of the nodes (the column blocks of a node's rows).
+// Returns false when the mesh cannot be tiled (a single node's elements exceed the budget, counters overflow).
+bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndofpn, const double* coords,
+                 const int32_t* conn, const int32_t* n2e_ptr, const int32_t* n2e_ent, const int64_t* nb_ptr,
+                 const int32_t* nb, int rec_doubles, int node_doubles, int lds_budget, TileSet& out);
+
+}  // namespace fa

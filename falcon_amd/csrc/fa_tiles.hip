@@ -1,0 +1,271 @@
+// fa_tiles.hip -- host-side construction of the node tiles (see fa_tiles.h, fa_tile_impl.h).  Host code only.
+#include "fa_tiles.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+#include "fa_internal.h"
+
+namespace fa {
+namespace {
+
+template <class F>
+void par_for(int64_t n, F&& body) {
+  unsigned hw = std::thread::hardware_concurrency();
+  int nt = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, n / 64));
+  if (nt <= 1) { body(0, n); return; }
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; t++) {
+    const int64_t b = t * chunk, e = std::min(n, b + chunk);
+    if (b >= e) break;
+    th.emplace_back([&body, b, e] { body(b, e); });
+  }
+  for (auto& x : th) x.join();
+}
+
+inline uint64_t spread3(uint64_t v) {                  // 21 bits -> every third bit
+  v &= 0x1FFFFFULL;
+  v = (v | (v << 32)) & 0x1F00000000FFFFULL;
+  v = (v | (v << 16)) & 0x1F0000FF0000FFULL;
+  v = (v | (v << 8)) & 0x100F00F00F00F00FULL;
+  v = (v | (v << 4)) & 0x10C30C30C30C30C3ULL;
+  v = (v | (v << 2)) & 0x1249249249249249ULL;
+  return v;
+}
+inline uint64_t spread2(uint64_t v) {                  // 31 bits -> every second bit
+  v &= 0x7FFFFFFFULL;
+  v = (v | (v << 16)) & 0x0000FFFF0000FFFFULL;
+  v = (v | (v << 8)) & 0x00FF00FF00FF00FFULL;
+  v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+  v = (v | (v << 2)) & 0x3333333333333333ULL;
+  v = (v | (v << 1)) & 0x5555555555555555ULL;
+  return v;
+}
+
+struct Cutter {                                        // greedy cut of the sorted node sequence
+  int64_t nnode, nel; int npe, nip, ndofpn, rec_doubles, node_doubles, lds_budget, tabn;
+  const int32_t* conn; const int32_t* n2e_ptr; const int32_t* n2e_ent; const int64_t* nb_ptr;
+  const std::vector<int32_t>& order; const std::vector<uint64_t>& key;
+  std::vector<int32_t> estamp, nstamp;
+
+  int64_t bytes(int64_t n_el, int64_t n_all, int64_t n_own) const {
+    return 8 * (n_el * tile_slot_doubles(nip, rec_doubles) + n_all * node_doubles + n_own * ndofpn + tabn) + 2 * n_el * npe + 16;
+  }
+  // Tiles end where the Morton cell of 2^L codes ends (once half full) or where the LDS budget / counters say so.
+  // Returns false if one node alone does not fit.  starts: first position of every tile in `order` (+ sentinel).
+  bool cut(int L, int64_t upto, std::vector<int64_t>& starts, std::vector<int32_t>* counts, int64_t& by_limit) {
+    estamp.assign((size_t)nel, -1); nstamp.assign((size_t)nnode, -1);
+    starts.clear(); by_limit = 0;
+    if (counts) counts->clear();
+    int32_t cur = 0;
+    int64_t n_own = 0, n_all = 0, n_el = 0, n_pairs = 0, n_ents = 0;
+    uint64_t cell0 = 0;
+    std::vector<int32_t> undo_e, undo_n;
+    auto close = [&]() {
+      if (counts) { counts->push_back((int32_t)n_own); counts->push_back((int32_t)n_all); counts->push_back((int32_t)n_el);
+                    counts->push_back((int32_t)n_pairs); counts->push_back((int32_t)n_ents); }
+      cur++; n_own = n_all = n_el = n_pairs = n_ents = 0;
+    };
+    const int64_t min_own = (L >= 1) ? (int64_t(1) << (L - 1)) : 1;
+    for (int64_t i = 0; i < upto; i++) {
+      const int32_t n = order[(size_t)i];
+      const uint64_t cell = (L >= 63) ? 0 : (key[(size_t)i] >> L);
+      if (n_own > 0 && cell != cell0 && n_own >= min_own) close();
+      for (int attempt = 0; attempt < 2; attempt++) {
+        if (n_own == 0) { starts.push_back(i); cell0 = cell; }
+        undo_e.clear(); undo_n.clear();
+        int64_t add_all = 0, add_el = 0;
+        if (nstamp[n] != cur) { nstamp[n] = cur; undo_n.push_back(n); add_all++; }
+        for (int32_t t = n2e_ptr[n]; t < n2e_ptr[n + 1]; t++) {
+          const int32_t el = n2e_ent[t] / npe;
+          if (estamp[el] == cur) continue;
+          estamp[el] = cur; undo_e.push_back(el); add_el++;
+          for (int a = 0; a < npe; a++) {
+            const int32_t m = conn[(int64_t)el * npe + a];
+            if (nstamp[m] != cur) { nstamp[m] = cur; undo_n.push_back(m); add_all++; }
+          }
+        }
+        const int64_t deg = nb_ptr[n + 1] - nb_ptr[n], val = n2e_ptr[n + 1] - n2e_ptr[n];
+        const bool fits = bytes(n_el + add_el, n_all + add_all, n_own + 1) <= lds_budget && n_all + add_all <= 65535 &&
+                          n_el + add_el <= 65535 && n_pairs + deg <= 2000000 && val <= 255;
+        if (fits) {
+          n_own++; n_all += add_all; n_el += add_el; n_pairs += deg; n_ents += val * npe;
+          break;
+        }
+        for (int32_t e : undo_e) estamp[e] = -1;
+        for (int32_t m : undo_n) nstamp[m] = -1;
+        if (n_own == 0) return false;                  // a single node does not fit
+        close(); by_limit++;
+      }
+    }
+    if (n_own > 0) close();
+    starts.push_back(upto);
+    return true;
+  }
+};
+
+}  // namespace
+
+bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndofpn, const double* coords,
+                 const int32_t* conn, const int32_t* n2e_ptr, const int32_t* n2e_ent, const int64_t* nb_ptr,
+                 const int32_t* nb, int rec_doubles, int node_doubles, int lds_budget, TileSet& T) {
+  if (nnode <= 0 || nel <= 0 || npe > 255) return false;
+  // ---- spatial order: Morton code of the coordinates quantised to the mean node spacing ----
+  double lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+  for (int d = 0; d < rank; d++) { lo[d] = hi[d] = coords[d]; }
+  for (int64_t n = 0; n < nnode; n++)
+    for (int d = 0; d < rank; d++) { lo[d] = std::min(lo[d], coords[n * rank + d]); hi[d] = std::max(hi[d], coords[n * rank + d]); }
+  double vol = 1.0, ext = 0.0;
+  for (int d = 0; d < rank; d++) ext = std::max(ext, hi[d] - lo[d]);
+  if (!(ext > 0.0)) return false;
+  int live = 0;
+  for (int d = 0; d < rank; d++) if (hi[d] - lo[d] > 1e-12 * ext) { vol *= hi[d] - lo[d]; live++; }
+  const double h = std::pow(vol / (double)nnode, 1.0 / std::max(live, 1));
+  const uint64_t qmax = (rank == 3) ? 0x1FFFFFULL : 0x7FFFFFFFULL;
+  std::vector<uint64_t> code((size_t)nnode);
+  par_for(nnode, [&](int64_t b, int64_t e) {
+    for (int64_t n = b; n < e; n++) {
+      uint64_t q[3] = { 0, 0, 0 };
+      for (int d = 0; d < rank; d++) {
+        const double v = std::floor((coords[n * rank + d] - lo[d]) / h + 0.5);
+        q[d] = (uint64_t)std::min<double>(std::max(v, 0.0), (double)qmax);
+      }
+      code[(size_t)n] = (rank == 3) ? (spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2))
+                                    : (spread2(q[0]) | (spread2(q[1]) << 1));
+    }
+  });
+  std::vector<int32_t> order((size_t)nnode);
+  for (int64_t n = 0; n < nnode; n++) order[(size_t)n] = (int32_t)n;
+  std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return code[a] != code[b] ? code[a] < code[b] : a < b; });
+  std::vector<uint64_t> key((size_t)nnode);
+  for (int64_t i = 0; i < nnode; i++) key[(size_t)i] = code[order[(size_t)i]];
+  code.clear(); code.shrink_to_fit();
+
+  const int tabn = nip * npe * (1 + rank) + nip;
+  Cutter C{ nnode, nel, npe, nip, ndofpn, rec_doubles, node_doubles, lds_budget, tabn, conn, n2e_ptr, n2e_ent, nb_ptr, order, key, {}, {} };
+  // ---- cell size: the Morton cell (or none: tiles filled to the budget) that evaluates the fewest elements per owned node ----
+  std::vector<int64_t> starts; int64_t by_limit = 0;
+  const int64_t sample = std::min<int64_t>(nnode, 200000);
+  int L = 63;
+  {
+    std::vector<int32_t> cs;
+    double best = 1e300;
+    const int cand[] = { 63, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2 };
+    for (int tryL : cand) {
+      if (!C.cut(tryL, sample, starts, &cs, by_limit)) return false;
+      double el = 0.0, own = 0.0;
+      for (size_t t = 0; t + 4 < cs.size() + 1; t += 5) { own += cs[t]; el += cs[t + 2]; }
+      const double score = el / std::max(own, 1.0);
+      if (score < best * 0.999) { best = score; L = tryL; }
+    }
+  }
+  std::vector<int32_t> counts;
+  if (!C.cut(L, nnode, starts, &counts, by_limit)) return false;
+  const int64_t ntile = (int64_t)starts.size() - 1;
+  if (ntile <= 0 || ntile > 0x7FFFFFF0LL) return false;
+  C.estamp.clear(); C.estamp.shrink_to_fit(); C.nstamp.clear(); C.nstamp.shrink_to_fit();
+
+  // ---- offsets ----
+  std::vector<int64_t> o_node((size_t)ntile + 1, 0), o_el((size_t)ntile + 1, 0), o_pair((size_t)ntile + 1, 0), o_ent((size_t)ntile + 1, 0);
+  int64_t max_bytes = 0;
+  for (int64_t t = 0; t < ntile; t++) {
+    const int32_t* c = counts.data() + t * 5;
+    o_node[t + 1] = o_node[t] + c[1]; o_el[t + 1] = o_el[t] + c[2]; o_pair[t + 1] = o_pair[t] + c[3]; o_ent[t + 1] = o_ent[t] + c[4];
+    max_bytes = std::max(max_bytes, C.bytes(c[2], c[1], c[0]));
+  }
+  const int64_t lim = 0x7FFFFFF0LL;
+  if (o_node[ntile] > lim || o_el[ntile] * npe > lim || o_pair[ntile] * 2 > lim || o_ent[ntile] > lim) return false;
+  T.ntile = (int)ntile; T.lds_bytes = (int)max_bytes;
+  T.tinfo.assign((size_t)ntile * kTileInfo, 0);
+  T.tnodes.assign((size_t)o_node[ntile], 0); T.telems.assign((size_t)o_el[ntile], 0);
+  T.tconn.assign((size_t)o_el[ntile] * npe, 0);
+  T.tpairs.assign((size_t)o_pair[ntile] * 2, 0); T.tents.assign((size_t)o_ent[ntile], 0);
+  T.point_redundancy = (double)o_el[ntile] / (double)nel;
+
+  // ---- fill ----
+  par_for(ntile, [&](int64_t tb, int64_t te) {
+    std::vector<int32_t> els, halo;
+    std::vector<std::pair<int32_t, int32_t>> lookup;   // (node, local index), sorted by node
+    struct PairTmp { uint32_t w0; uint32_t first, cnt; };
+    std::vector<PairTmp> pt; std::vector<uint32_t> ent;
+    for (int64_t t = tb; t < te; t++) {
+      const int32_t* c = counts.data() + t * 5;
+      const int n_own = c[0], n_all = c[1], n_el = c[2];
+      const int32_t* own = order.data() + starts[(size_t)t];
+      int32_t* ti = T.tinfo.data() + t * kTileInfo;
+      ti[0] = (int32_t)o_node[t]; ti[1] = n_all; ti[2] = n_own; ti[3] = (int32_t)o_el[t]; ti[4] = n_el;
+      ti[5] = (int32_t)o_pair[t]; ti[6] = c[3]; ti[7] = (int32_t)o_ent[t];
+      els.clear();
+      for (int i = 0; i < n_own; i++)
+        for (int32_t k = n2e_ptr[own[i]]; k < n2e_ptr[own[i] + 1]; k++) els.push_back(n2e_ent[k] / npe);
+      std::sort(els.begin(), els.end()); els.erase(std::unique(els.begin(), els.end()), els.end());
+      lookup.clear();
+      for (int i = 0; i < n_own; i++) lookup.emplace_back(own[i], i);
+      std::sort(lookup.begin(), lookup.end());
+      auto find_local = [&](int32_t node) -> int {
+        auto it = std::lower_bound(lookup.begin(), lookup.end(), std::make_pair(node, (int32_t)-1));
+        return (it != lookup.end() && it->first == node) ? it->second : -1;
+      };
+      halo.clear();
+      for (int32_t el : els)
+        for (int a = 0; a < npe; a++) { const int32_t m = conn[(int64_t)el * npe + a]; if (find_local(m) < 0) halo.push_back(m); }
+      std::sort(halo.begin(), halo.end()); halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
+      int32_t* tn = T.tnodes.data() + o_node[t];
+      for (int i = 0; i < n_own; i++) tn[i] = own[i];
+      for (size_t i = 0; i < halo.size(); i++) { tn[n_own + i] = halo[i]; lookup.emplace_back(halo[i], n_own + (int32_t)i); }
+      std::sort(lookup.begin(), lookup.end());
+      int32_t* tel = T.telems.data() + o_el[t];
+      uint16_t* tc = T.tconn.data() + o_el[t] * npe;
+      for (size_t s = 0; s < els.size(); s++) {
+        const int32_t* cn = conn + (int64_t)els[s] * npe;
+        const int first = find_local(cn[0]);
+        tel[s] = els[s] | ((first >= 0 && first < n_own) ? (int32_t)0x80000000 : 0);
+        for (int a = 0; a < npe; a++) tc[s * npe + a] = (uint16_t)find_local(cn[a]);
+      }
+      // pairs (owned node, neighbour) with the elements that hold both, element-ascending
+      pt.clear(); ent.clear();
+      for (int ia = 0; ia < n_own; ia++) {
+        const int32_t a = own[ia];
+        const int64_t deg = nb_ptr[a + 1] - nb_ptr[a];
+        for (int64_t k = 0; k < deg; k++) {
+          const int32_t b = nb[nb_ptr[a] + k];
+          PairTmp q; q.first = (uint32_t)ent.size(); q.cnt = 0;
+          for (int32_t u = n2e_ptr[a]; u < n2e_ptr[a + 1]; u++) {
+            const int32_t el = n2e_ent[u] / npe, la = n2e_ent[u] - el * npe;
+            const int32_t* cn = conn + (int64_t)el * npe;
+            for (int lb = 0; lb < npe; lb++)
+              if (cn[lb] == b) {
+                const uint32_t slot = (uint32_t)(std::lower_bound(els.begin(), els.end(), el) - els.begin());
+                ent.push_back(slot | ((uint32_t)la << 16) | ((uint32_t)lb << 24));
+                q.cnt++;
+                break;
+              }
+          }
+          q.w0 = (uint32_t)ia | ((uint32_t)k << 16) | (q.cnt << 24);
+          pt.push_back(q);
+        }
+      }
+      // lanes of a wave: equal element counts (uniform trip count), then equal first elements (their record reads
+      // become LDS broadcasts instead of bank conflicts)
+      std::stable_sort(pt.begin(), pt.end(), [&](const PairTmp& x, const PairTmp& y) {
+        if (x.cnt != y.cnt) return x.cnt > y.cnt;
+        if (x.cnt == 0) return false;
+        return (ent[x.first] & 0xFFFFu) < (ent[y.first] & 0xFFFFu);
+      });
+      uint32_t* tp = T.tpairs.data() + o_pair[t] * 2;
+      uint32_t* tq = T.tents.data() + o_ent[t];
+      uint32_t run = 0;
+      for (size_t i = 0; i < pt.size(); i++) {
+        tp[2 * i] = pt[i].w0; tp[2 * i + 1] = run;
+        for (uint32_t k = 0; k < pt[i].cnt; k++) tq[run + k] = ent[pt[i].first + k];
+        run += pt[i].cnt;
+      }
+    }
+  });
+  return true;
+}
+
+}  // namespace fa
