@@ -1,4 +1,4 @@
-// fa_tile_impl.h -- tile kernel for the 3-D and higher-order shapes (GET_MATRIX0 passes).
+// fa_tile_impl.h -- tile kernel for Hex8 and the higher-order shapes.
 //
 // A tile is a compact set of owned nodes (a block of the spatially sorted node sequence, built in fa_api.hip)
 // together with every element that touches one of them.  One workgroup per tile:
@@ -13,6 +13,7 @@
 //                     elements that hold both nodes and over their Gauss points (:713-722), read from the LDS
 //                     records, and written straight to its CSR entries.  Every entry of K has exactly one writer:
 //                     no atomics, no LDS image of the rows, deterministic summation order (element-ascending).
+//                     GET_INT_VECTOR passes (WANT_K = false) stop after phase 1 and keep no records.
 // Lanes of phase 2 are sorted by their element count (8/4/2/1 for a structured Hex8 mesh) so that a wave does
 // uniform work.  Registers stay low (16 accumulators), which is what the row kernel cannot offer in 3-D, where
 // its 4 x 32 row block pins it at one wave per SIMD.
@@ -242,13 +243,8 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
 
   // ---- phase 2: node-pair blocks of K1..K4 (PhaseFractureModel.cpp:713-722) ----
   if constexpr (WANT_K) {
-#ifdef FA_TILE_TAB_GLOBAL                              // shape tables through the vector-memory pipe (L1 hits), records from LDS
-  const double* __restrict__ tab2N = P.tab;
-  const double* __restrict__ tab2D = P.tab + NIP * NPE;
-#else
   const double* tab2N = tabN;
   const double* tab2D = tabD;
-#endif
   for (int p = tid; p < n_pairs; p += BLK) {
     const uint32_t w0 = P.tpairs[((int64_t)pair_off + p) * 2], w1 = P.tpairs[((int64_t)pair_off + p) * 2 + 1];
     const int ia = (int)(w0 & 0xFFFFu), kpos = (int)((w0 >> 16) & 0xFFu), cnt = (int)(w0 >> 24);
