@@ -659,9 +659,14 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     if (P.canon && wanted && nel > 0) {
       const bool keepK = P.keep2 || P.keep3;
       const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE;
+      // lane order of the pair phase: sorted by element count with (a,b)/(b,a) sharing a lane, except on triangle
+      // meshes, where (node, neighbour) order with the staged row write-out measured faster (Triangle6: 1.9 / 2.45 ms)
+      const bool tri = p->shape == FA_TRI3_G1 || p->shape == FA_TRI3_G3 || p->shape == FA_TRI6_G3;
+      const bool row_order = getenv("FA_TILE_ORDER") ? atoi(getenv("FA_TILE_ORDER")) != 0 : tri;
+      P.tile_stage = row_order ? 1 : 0;
       c->tile_path = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
                                      nb_ptr.data(), nb.data(), fa::tile_rec_doubles(rank, c->fam, keepK),
-                                     fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0), fa::kTileLds, ts);
+                                     fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0), fa::kTileLds, row_order, ts);
       if (c->tile_path) { c->ntile3 = ts.ntile; P.ntile3 = ts.ntile; P.tile_lds = ts.lds_bytes; }
       // GET_INT_VECTOR passes keep no records, so a tile set sized for GET_MATRIX0 pays its Gauss-point redundancy for
       // nothing: measured faster than the row / cooperative kernels up to ~3 evaluations per point (Hex20 Gauss3: 5)

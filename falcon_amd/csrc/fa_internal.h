@@ -64,6 +64,8 @@ constexpr int tile_rec_doubles(int rank, int fam, bool keep) {
 // doubles of one element slot (nip records): odd, so that lanes reading the same field of different slots spread
 // over the LDS banks
 constexpr int tile_slot_doubles(int nip, int rec_doubles) { return (nip * rec_doubles) | 1; }
+// bytes of the wave-private staging rows of the row-ordered write-out (64 chunks of a row + 64 row bases per wave)
+constexpr int tile_stage_bytes(int ndofpn) { return (kTileBlock / 64) * (64 * ndofpn + 64) * 8; }
 // doubles staged per tile node: x, u and (phase-field families) phi; the Ext variants add phi of state0 and of
 // state00 / stateExt_ in an array of their own
 constexpr int tile_node_doubles(int rank, bool pf) { return 2 * rank + (pf ? 1 : 0); }
@@ -108,7 +110,7 @@ struct Params {
   const int32_t*  tnodes;    // tile nodes, owned ones first
   const int32_t*  telems;    // tile elements, ascending; bit 31: this tile stores the element's per-point outputs
   const uint16_t* tconn;     // per tile element: npe indices into the tile's node list
-  const uint32_t* tpairs;    // per (owned node, neighbour): owned index | position in the row << 16 | elements << 24, entry offset
+  const uint32_t* tpairs;    // 4 words per pair lane: owned index | position in the row << 16 | elements << 24, entry offset, mirror, pad
   const uint32_t* tents;     // per (pair, shared element): slot | local node a << 16 | local node b << 24
   const double*  tab;        // shape tables: N[nip][npe], dN[nip][npe][rank], w[nip]
   // ---- vectors (device) ----
@@ -124,7 +126,7 @@ struct Params {
   double*        f;
   // ---- sizes / switches ----
   int64_t nnode, nel;
-  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2, ntile3, tile_lds;
+  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2, ntile3, tile_lds, tile_stage;
   int32_t cnt[4];            // entries per neighbour node in a row of dof type i
   int32_t off[4][4];         // offset of column type j inside that group, -1 if not in the pattern
   // ---- constants ----

@@ -9,7 +9,7 @@
 //                     the constitutive coefficients -- and adds its f_int contributions for the owned nodes to an
 //                     LDS image of the tile's f rows.  Each point of an element is evaluated once per tile that
 //                     touches the element (1.5-2.5 times per pass instead of NPE times in the row kernel).
-//   phase 2  pairs    one lane per (owned node a, neighbour b): the (rank+1)^2 block of K1..K4 summed over the
+//   phase 2  pairs    one lane per (owned node a, neighbour b) -- per unordered pair when both nodes are owned --: the (rank+1)^2 block of K1..K4 summed over the
 //                     elements that hold both nodes and over their Gauss points (:713-722), read from the LDS
 //                     records, and written straight to its CSR entries.  Every entry of K has exactly one writer:
 //                     no atomics, no LDS image of the rows, deterministic summation order (element-ascending).
@@ -62,7 +62,9 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
   double* sExt = sNod + n_all * NODW;                 // phi of state0 / state00 (stateExt_), Ext variants only
   const bool ext_state = PF && (SP::model(P) == 2 || SP::model(P) == 3 || SP::model(P) >= 5);
   double* sF   = sExt + (ext_state ? 2 * n_all : 0);
-  double* sTab = sF + n_own * NDOF;
+  long long* sRow = reinterpret_cast<long long*>(sF + n_own * NDOF);   // first CSR entry of every owned node's first row
+  int* sDeg = reinterpret_cast<int*>(sRow + n_own);                    // neighbours of every owned node
+  double* sTab = reinterpret_cast<double*>(sRow + n_own) + (n_own + 1) / 2;
   uint16_t* sConn = (uint16_t*)(sTab + TABN);
   const double* tabN = sTab;
   const double* tabD = sTab + NIP * NPE;
@@ -82,6 +84,11 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
     }
   }
   for (int i = tid; i < n_own * NDOF; i += BLK) sF[i] = 0.0;
+  for (int i = tid; i < n_own; i += BLK) {
+    const int64_t r0 = (int64_t)P.tnodes[node_off + i] * NDOF;
+    const long long b0 = P.row_ptr[r0], b1 = P.row_ptr[r0 + 1];
+    sRow[i] = b0; sDeg[i] = (P.cnt[0] > 0) ? (int)((b1 - b0) / P.cnt[0]) : 0;
+  }
   for (int i = tid; i < TABN; i += BLK) sTab[i] = P.tab[i];
   for (int i = tid; i < n_el * NPE; i += BLK) sConn[i] = P.tconn[(int64_t)elem_off * NPE + i];
   __syncthreads();
@@ -245,18 +252,31 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
   if constexpr (WANT_K) {
   const double* tab2N = tabN;
   const double* tab2D = tabD;
-  for (int p = tid; p < n_pairs; p += BLK) {
-    const uint32_t w0 = P.tpairs[((int64_t)pair_off + p) * 2], w1 = P.tpairs[((int64_t)pair_off + p) * 2 + 1];
+  // wave-private staging rows for the coalesced write-out of row-ordered lanes (P.tile_stage)
+  double* stg = reinterpret_cast<double*>(sConn + ((n_el * NPE + 3) & ~3)) + (tid >> 6) * (64 * NDOF + 64);
+  long long* stg_base = reinterpret_cast<long long*>(stg + 64 * NDOF);
+  const int lane = tid & 63;
+  const uint4* __restrict__ prec = reinterpret_cast<const uint4*>(P.tpairs) + pair_off;
+  uint4 pw_next = (tid < n_pairs) ? prec[tid] : make_uint4(0u, 0u, 0u, 0u);
+  for (int p0 = 0; p0 < n_pairs; p0 += BLK) {           // uniform trip count: every lane of a wave takes part in the write-out
+    const int p = p0 + tid;
+    const bool active = p < n_pairs;
+    const uint4 pw = pw_next;
+    pw_next = (p + BLK < n_pairs) ? prec[p + BLK] : make_uint4(0u, 0u, 0u, 0u);   // next pass's record in flight
+    const uint32_t w0 = pw.x;
     const int ia = (int)(w0 & 0xFFFFu), kpos = (int)((w0 >> 16) & 0xFFu), cnt = (int)(w0 >> 24);
-    const uint32_t* __restrict__ ents = P.tents + (int64_t)ent_off + w1;
-    double Kuu[RANK][RANK], Kpp = 0.0, Kup[RANK], Kpu[RANK];
+    const uint32_t* __restrict__ ents = P.tents + (int64_t)ent_off + pw.y;
+    // b is owned by this tile as well: this lane also writes the block (b, a) -- K1 and K4 of it are the transposes
+    const bool mirror = (pw.z >> 31) != 0;
+    const int ib = (int)(pw.z & 0xFFFFu), kpos2 = (int)((pw.z >> 16) & 0xFFu);
+    double Kuu[RANK][RANK], Kpp = 0.0, Kup[RANK], Kpu[RANK], Kup2[RANK], Kpu2[RANK];
 #pragma unroll
     for (int i = 0; i < RANK; i++) {
-      Kup[i] = 0.0; Kpu[i] = 0.0;
+      Kup[i] = 0.0; Kpu[i] = 0.0; Kup2[i] = 0.0; Kpu2[i] = 0.0;
 #pragma unroll
       for (int j = 0; j < RANK; j++) Kuu[i][j] = 0.0;
     }
-    uint32_t ent_next = (cnt > 0) ? ents[0] : 0u;
+    uint32_t ent_next = pw.w;                            // the first entry travels in the pair record
 #pragma unroll 1
     for (int t = 0; t < cnt; t++) {
       const uint32_t ent = ent_next;
@@ -266,7 +286,7 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
       for (int ip = 0; ip < NIP; ip++) {
         const double* rec = sRec + slot * SLOTW + ip * RW;
         const double w = rec[TR::O_W];
-        double wga[RANK], gb[RANK];
+        double wga[RANK], gb[RANK], ga[RANK];
 #pragma unroll
         for (int i = 0; i < RANK; i++) {               // same expression as phase 1: the gradients are bit-identical
           double acca = 0.0, accb = 0.0;
@@ -275,7 +295,7 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
             acca += tab2D[(ip * NPE + la) * RANK + k] * rec[TR::O_INV + k * RANK + i];
             accb += tab2D[(ip * NPE + lb) * RANK + k] * rec[TR::O_INV + k * RANK + i];
           }
-          wga[i] = w * acca; gb[i] = accb;
+          wga[i] = w * acca; gb[i] = accb; ga[i] = acca;
         }
         if constexpr (FAM == FAM_PF_MIEHE) {
           double D[S][S];
@@ -341,56 +361,116 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
               const double dg = rec[TR::O_SP + S];
 #pragma unroll
               for (int i = 0; i < RANK; i++) Kup[i] += (dg * tt[i]) * Nb;
+              if (mirror) {                                             // K2 of (b, a)
+                double wgb[RANK];
+#pragma unroll
+                for (int i = 0; i < RANK; i++) wgb[i] = w * gb[i];
+                Bt_vec<RANK, S>(wgb, spv, tt);
+#pragma unroll
+                for (int i = 0; i < RANK; i++) Kup2[i] += (dg * tt[i]) * Na;
+              }
             }
             if (P.keep3) {                                              // K3 (:721)
               Bt_vec<RANK, S>(gb, spv, tt);
               const double dgl = rec[TR::O_SP + S + 1];
 #pragma unroll
               for (int j = 0; j < RANK; j++) Kpu[j] += (wNa * dgl) * tt[j];
+              if (mirror) {                                             // K3 of (b, a)
+                Bt_vec<RANK, S>(ga, spv, tt);
+#pragma unroll
+                for (int j = 0; j < RANK; j++) Kpu2[j] += ((w * Nb) * dgl) * tt[j];
+              }
             }
           }
         }
       }
     }
-    // ---- the block's CSR entries: rows of node a, columns of its kpos-th neighbour (canonical blocked layout) ----
-    const int64_t na = P.tnodes[node_off + ia];
-    auto put = [&](int i, int j, double v) {
-      const int o = P.off[i][j];
-      if (o < 0) return;
-      const int64_t q = P.row_ptr[na * NDOF + i] + (int64_t)kpos * P.cnt[i] + o;
-      P.K[q] = P.overwrite ? v : P.K[q] + v;
+    // ---- the block's CSR entries: rows of a node, columns of its kp-th neighbour (canonical blocked layout) ----
+    // first entry of row i of owned node io: the rows of a node follow each other, deg * cnt[i'] entries each
+    auto row_base = [&](int io, int i) -> long long {
+      long long b = sRow[io];
+      const int deg = sDeg[io];
+#pragma unroll
+      for (int r = 0; r < NDOF; r++) if (r < i) b += (long long)deg * P.cnt[r];
+      return b;
     };
-    if (NDOF == 4 && P.cnt[0] == 4 && P.cnt[3] == 4) {   // full 4x4 block: each row chunk is 32 bytes, 32-byte aligned
-      if constexpr (NDOF == 4) {
-        double blk[4][4];
+    auto emit = [&](int io, int kp, const double (&blk)[NDOF][NDOF]) {
+      if (NDOF == 4 && P.cnt[0] == 4 && P.cnt[3] == 4) {  // full 4x4 block: each row chunk is 32 bytes, 32-byte aligned
+        if constexpr (NDOF == 4) {
+          const long long b0 = sRow[io] + (long long)kp * 4, rs = (long long)sDeg[io] * 4;
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-#pragma unroll
-          for (int j = 0; j < 3; j++) blk[i][j] = Kuu[i][j];
-          blk[i][3] = (KEEP && P.keep2) ? Kup[i] : 0.0;
-          blk[3][i] = (KEEP && P.keep3) ? Kpu[i] : 0.0;
+          for (int i = 0; i < 4; i++) {
+            double2* q = reinterpret_cast<double2*>(P.K + b0 + i * rs);
+            double2 v0 = make_double2(blk[i][0], blk[i][1]), v1 = make_double2(blk[i][2], blk[i][3]);
+            if (!P.overwrite) { const double2 o0 = q[0], o1 = q[1]; v0.x += o0.x; v0.y += o0.y; v1.x += o1.x; v1.y += o1.y; }
+            q[0] = v0; q[1] = v1;
+          }
         }
-        blk[3][3] = Kpp;
+      } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          double2* q = reinterpret_cast<double2*>(P.K + P.row_ptr[na * 4 + i] + (int64_t)kpos * 4);
-          double2 v0 = make_double2(blk[i][0], blk[i][1]), v1 = make_double2(blk[i][2], blk[i][3]);
-          if (!P.overwrite) { const double2 o0 = q[0], o1 = q[1]; v0.x += o0.x; v0.y += o0.y; v1.x += o1.x; v1.y += o1.y; }
-          q[0] = v0; q[1] = v1;
+        for (int i = 0; i < NDOF; i++) {
+          const long long bi = row_base(io, i) + (long long)kp * P.cnt[i];
+#pragma unroll
+          for (int j = 0; j < NDOF; j++) {
+            const int o = P.off[i][j];
+            if (o < 0) continue;
+            P.K[bi + o] = P.overwrite ? blk[i][j] : P.K[bi + o] + blk[i][j];
+          }
         }
       }
-    } else {
+    };
+    double blk[NDOF][NDOF];
+#pragma unroll
+    for (int i = 0; i < RANK; i++) {
+#pragma unroll
+      for (int j = 0; j < RANK; j++) blk[i][j] = Kuu[i][j];
+      if constexpr (PF) {
+        blk[i][RANK] = (KEEP && P.keep2) ? Kup[i] : 0.0;
+        blk[RANK][i] = (KEEP && P.keep3) ? Kpu[i] : 0.0;
+      }
+    }
+    if constexpr (PF) blk[RANK][RANK] = Kpp;
+    if (P.tile_stage) {
+      // Lanes are in (node, neighbour) order: the chunks of one CSR row held by consecutive lanes are consecutive in
+      // memory.  Row by row they pass through LDS so that a store instruction writes 64 consecutive doubles
+      // (LDS operations of one wave complete in order; the wave barriers only pin the compiler's schedule).
+#pragma unroll
+      for (int i = 0; i < NDOF; i++) {
+        const int ci = P.cnt[i];
+        if (ci == 0) continue;
+        if (active) {
+#pragma unroll
+          for (int j = 0; j < NDOF; j++) { const int o = P.off[i][j]; if (o >= 0) stg[lane * ci + o] = blk[i][j]; }
+          stg_base[lane] = row_base(ia, i) + (long long)kpos * ci;
+        } else {
+          stg_base[lane] = -1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int d = lane; d < 64 * ci; d += 64) {
+          const int owner = (ci == 3) ? d / 3 : ((ci == 4) ? (d >> 2) : ((ci == 2) ? (d >> 1) : ((ci == 1) ? d : d / ci)));
+          const long long b = stg_base[owner];
+          if (b >= 0) {
+            const int64_t q = b + (d - owner * ci);
+            P.K[q] = P.overwrite ? stg[d] : P.K[q] + stg[d];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      continue;
+    }
+    if (!active) continue;
+    emit(ia, kpos, blk);
+    if (mirror) {
 #pragma unroll
       for (int i = 0; i < RANK; i++) {
 #pragma unroll
-        for (int j = 0; j < RANK; j++) put(i, j, Kuu[i][j]);
-        if constexpr (PF) put(i, RANK, (KEEP && P.keep2) ? Kup[i] : 0.0);
+        for (int j = 0; j < RANK; j++) blk[i][j] = Kuu[j][i];
+        if constexpr (PF) {
+          blk[i][RANK] = (KEEP && P.keep2) ? Kup2[i] : 0.0;
+          blk[RANK][i] = (KEEP && P.keep3) ? Kpu2[i] : 0.0;
+        }
       }
-      if constexpr (PF) {
-#pragma unroll
-        for (int j = 0; j < RANK; j++) put(RANK, j, (KEEP && P.keep3) ? Kpu[j] : 0.0);
-        put(RANK, RANK, Kpp);
-      }
+      emit(ib, kpos2, blk);
     }
   }
   }

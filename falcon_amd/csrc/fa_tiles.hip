@@ -46,13 +46,13 @@ inline uint64_t spread2(uint64_t v) {                  // 31 bits -> every secon
 }
 
 struct Cutter {                                        // greedy cut of the sorted node sequence
-  int64_t nnode, nel; int npe, nip, ndofpn, rec_doubles, node_doubles, lds_budget, tabn;
+  int64_t nnode, nel; int npe, nip, ndofpn, rec_doubles, node_doubles, lds_budget, tabn, extra_bytes;
   const int32_t* conn; const int32_t* n2e_ptr; const int32_t* n2e_ent; const int64_t* nb_ptr;
   const std::vector<int32_t>& order; const std::vector<uint64_t>& key;
   std::vector<int32_t> estamp, nstamp;
 
   int64_t bytes(int64_t n_el, int64_t n_all, int64_t n_own) const {
-    return 8 * (n_el * tile_slot_doubles(nip, rec_doubles) + n_all * node_doubles + n_own * ndofpn + tabn) + 2 * n_el * npe + 16;
+    return 8 * (n_el * tile_slot_doubles(nip, rec_doubles) + n_all * node_doubles + n_own * (ndofpn + 2) + tabn) + 2 * n_el * npe + 16 + extra_bytes;
   }
   // Tiles end where the Morton cell of 2^L codes ends (once half full) or where the LDS budget / counters say so.
   // Returns false if one node alone does not fit.  starts: first position of every tile in `order` (+ sentinel).
@@ -111,7 +111,7 @@ struct Cutter {                                        // greedy cut of the sort
 
 bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndofpn, const double* coords,
                  const int32_t* conn, const int32_t* n2e_ptr, const int32_t* n2e_ent, const int64_t* nb_ptr,
-                 const int32_t* nb, int rec_doubles, int node_doubles, int lds_budget, TileSet& T) {
+                 const int32_t* nb, int rec_doubles, int node_doubles, int lds_budget, bool row_order, TileSet& T) {
   if (nnode <= 0 || nel <= 0 || npe > 255) return false;
   // ---- spatial order: Morton code of the coordinates quantised to the mean node spacing ----
   double lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
@@ -145,7 +145,7 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
   code.clear(); code.shrink_to_fit();
 
   const int tabn = nip * npe * (1 + rank) + nip;
-  Cutter C{ nnode, nel, npe, nip, ndofpn, rec_doubles, node_doubles, lds_budget, tabn, conn, n2e_ptr, n2e_ent, nb_ptr, order, key, {}, {} };
+  Cutter C{ nnode, nel, npe, nip, ndofpn, rec_doubles, node_doubles, lds_budget, tabn, row_order ? tile_stage_bytes(ndofpn) : 0, conn, n2e_ptr, n2e_ent, nb_ptr, order, key, {}, {} };
   // ---- cell size: the Morton cell (or none: tiles filled to the budget) that evaluates the fewest elements per owned node ----
   std::vector<int64_t> starts; int64_t by_limit = 0;
   const int64_t sample = std::min<int64_t>(nnode, 200000);
@@ -177,19 +177,19 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
     max_bytes = std::max(max_bytes, C.bytes(c[2], c[1], c[0]));
   }
   const int64_t lim = 0x7FFFFFF0LL;
-  if (o_node[ntile] > lim || o_el[ntile] * npe > lim || o_pair[ntile] * 2 > lim || o_ent[ntile] > lim) return false;
+  if (o_node[ntile] > lim || o_el[ntile] * npe > lim || o_pair[ntile] * 4 > lim || o_ent[ntile] > lim) return false;
   T.ntile = (int)ntile; T.lds_bytes = (int)max_bytes;
   T.tinfo.assign((size_t)ntile * kTileInfo, 0);
   T.tnodes.assign((size_t)o_node[ntile], 0); T.telems.assign((size_t)o_el[ntile], 0);
   T.tconn.assign((size_t)o_el[ntile] * npe, 0);
-  T.tpairs.assign((size_t)o_pair[ntile] * 2, 0); T.tents.assign((size_t)o_ent[ntile], 0);
+  T.tpairs.assign((size_t)o_pair[ntile] * 4, 0); T.tents.assign((size_t)o_ent[ntile], 0);
   T.point_redundancy = (double)o_el[ntile] / (double)nel;
 
   // ---- fill ----
   par_for(ntile, [&](int64_t tb, int64_t te) {
     std::vector<int32_t> els, halo;
     std::vector<std::pair<int32_t, int32_t>> lookup;   // (node, local index), sorted by node
-    struct PairTmp { uint32_t w0; uint32_t first, cnt; };
+    struct PairTmp { uint32_t w0, w2; uint32_t first, cnt; bool diag; };
     std::vector<PairTmp> pt; std::vector<uint32_t> ent;
     for (int64_t t = tb; t < te; t++) {
       const int32_t* c = counts.data() + t * 5;
@@ -232,7 +232,14 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
         const int64_t deg = nb_ptr[a + 1] - nb_ptr[a];
         for (int64_t k = 0; k < deg; k++) {
           const int32_t b = nb[nb_ptr[a] + k];
-          PairTmp q; q.first = (uint32_t)ent.size(); q.cnt = 0;
+          PairTmp q; q.first = (uint32_t)ent.size(); q.cnt = 0; q.w2 = 0;
+          const int ib = find_local(b);
+          if (!row_order && ib >= 0 && ib < n_own && ib != ia) {   // both owned: one lane for (a, b) and (b, a)
+            if (ib < ia) continue;
+            const int32_t* lo2 = nb + nb_ptr[b]; const int32_t* hi2 = nb + nb_ptr[b + 1];
+            const uint32_t k2 = (uint32_t)(std::lower_bound(lo2, hi2, a) - lo2);
+            q.w2 = (uint32_t)ib | (k2 << 16) | 0x80000000u;
+          }
           for (int32_t u = n2e_ptr[a]; u < n2e_ptr[a + 1]; u++) {
             const int32_t el = n2e_ent[u] / npe, la = n2e_ent[u] - el * npe;
             const int32_t* cn = conn + (int64_t)el * npe;
@@ -245,21 +252,32 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
               }
           }
           q.w0 = (uint32_t)ia | ((uint32_t)k << 16) | (q.cnt << 24);
+          q.diag = (ib == ia);
           pt.push_back(q);
         }
       }
-      // lanes of a wave: equal element counts (uniform trip count), then equal first elements (their record reads
-      // become LDS broadcasts instead of bank conflicts)
-      std::stable_sort(pt.begin(), pt.end(), [&](const PairTmp& x, const PairTmp& y) {
-        if (x.cnt != y.cnt) return x.cnt > y.cnt;
-        if (x.cnt == 0) return false;
-        return (ent[x.first] & 0xFFFFu) < (ent[y.first] & 0xFFFFu);
-      });
-      uint32_t* tp = T.tpairs.data() + o_pair[t] * 2;
+      if (row_order) {
+        // the diagonal blocks first (they hold the most elements), then the others in (node, neighbour) order: the
+        // lanes of a wave then write consecutive chunks of the same CSR rows
+        std::stable_sort(pt.begin(), pt.end(), [&](const PairTmp& x, const PairTmp& y) {
+          if (x.diag != y.diag) return x.diag;
+          return x.diag && x.cnt > y.cnt;
+        });
+      } else {
+        // lanes of a wave: equal element counts (uniform trip count), then equal first elements (their record reads
+        // become LDS broadcasts instead of bank conflicts)
+        std::stable_sort(pt.begin(), pt.end(), [&](const PairTmp& x, const PairTmp& y) {
+          if (x.cnt != y.cnt) return x.cnt > y.cnt;
+          if (x.cnt == 0) return false;
+          return (ent[x.first] & 0xFFFFu) < (ent[y.first] & 0xFFFFu);
+        });
+      }
+      ti[6] = (int32_t)pt.size();
+      uint32_t* tp = T.tpairs.data() + o_pair[t] * 4;
       uint32_t* tq = T.tents.data() + o_ent[t];
       uint32_t run = 0;
       for (size_t i = 0; i < pt.size(); i++) {
-        tp[2 * i] = pt[i].w0; tp[2 * i + 1] = run;
+        tp[4 * i] = pt[i].w0; tp[4 * i + 1] = run; tp[4 * i + 2] = pt[i].w2; tp[4 * i + 3] = pt[i].cnt ? ent[pt[i].first] : 0u;
         for (uint32_t k = 0; k < pt[i].cnt; k++) tq[run + k] = ent[pt[i].first + k];
         run += pt[i].cnt;
       }
