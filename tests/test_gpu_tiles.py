@@ -1,0 +1,84 @@
+"""Tile kernel (falcon_amd/csrc/fa_tile_impl.h) on meshes large enough for hundreds of tiles with halos: parity with the
+oracle to 1e-12 through the C ABI, for the shapes it is the default of, with shuffled node numbering, the Ext state
+arrays, off-diagonal blocks, += semantics, GET_INT_VECTOR passes, and bitwise repeatability of K (every entry has one
+writer and a fixed summation order)."""
+import numpy as np
+import pytest
+
+from falcon_amd import capi, meshgen
+from oracle import pyoracle as po
+from tests.test_gpu_parity import rel_rowmax_err, vec_err
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # shape, mesh, model, material, keep
+    (capi.HEX8_G2, lambda: meshgen.grid_hex8(14, 12, 11), capi.PHASE_FRACTURE, capi.AMOR_PHASE, 0),
+    (capi.HEX8_G2, lambda: meshgen.grid_hex8(9, 10, 12), capi.PHASE_FRACTURE_EXTIT, capi.BOURDIN_PHASE, 1),
+    (capi.HEX8_G2, lambda: meshgen.grid_hex8(12, 9, 9), capi.LINEAR_ELASTICITY, capi.HOOKE, 0),
+    (capi.HEX20_G2, lambda: meshgen.grid_hex20(6, 5, 5), capi.PHASE_FRACTURE, capi.MIEHE_PHASE, 1),
+    (capi.HEX20_G3, lambda: meshgen.grid_hex20(5, 4, 4), capi.LINEAR_ELASTICITY, capi.HOOKE, 0),
+    (capi.QUAD8_G3, lambda: meshgen.grid_quad8(40, 33), capi.PHASE_FRACTURE, capi.AMOR_PHASE, 1),
+    (capi.QUAD8_G2, lambda: meshgen.grid_quad8(31, 37), capi.MICRO_PHASE_FRACTURE_EXT, capi.MIEHE_PHASE, 0),
+    (capi.TRI6_G3, lambda: meshgen.grid_tri6(35, 41), capi.PHASE_FRACTURE_EXT, capi.AMOR_PHASE, 0),
+    (capi.TRI3_G3, lambda: meshgen.grid_tri3(50, 45), capi.PHASE_FRACTURE, capi.MIEHE_PHASE, 1),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_tile_kernel_parity_on_many_tiles(case):
+    import torch
+    shape, mesh, model, material, keep = CASES[case]
+    coords, conn = mesh()
+    linear = shape in (capi.HEX8_G2, capi.TRI3_G3)
+    coords = meshgen.distort(coords, conn, 0.12 if linear else 0.05, 3)
+    coords, conn, _ = meshgen.shuffle_nodes(coords, conn, 5)               # the builder sorts spatially, whatever the numbering
+    rank = coords.shape[1]
+    pf = model != capi.LINEAR_ELASTICITY
+    nd = rank + (1 if pf else 0)
+    micro = model >= capi.MICRO_PHASE_FRACTURE
+    kw = dict(young=210.0, poisson=0.3, frac_type=capi.AT2, gc=2.7e-3, l0=0.2, beta=250.0 if micro else 6500.0, keep_off_diags=keep)
+    cfg = po.make_config(shape, model, material, **kw)
+    asm = capi.Assembler(shape, model, material, coords, conn, **kw)
+    rp, ci = asm.pattern()
+    rpo, cio = po.pattern(coords.shape[0], conn, nd, rank, po.PATTERN_FULL, po.keep_code(cfg))
+    assert np.array_equal(rp, rpo) and np.array_equal(ci, cio)
+    rng = np.random.default_rng(11)
+    st = meshgen.smooth_state(coords, nd, seed=2, amp=5e-3, noise=1e-4, l0=0.3)
+    st0 = st.copy(); st00 = st.copy()
+    if pf:
+        st0[rank::nd] += rng.uniform(-0.02, 0.02, coords.shape[0]); st00[rank::nd] += rng.uniform(-0.02, 0.02, coords.shape[0])
+    hist = None
+    if model in (capi.PHASE_FRACTURE,) or micro:
+        hist = rng.uniform(0, 0.3 if micro else 2e-3, conn.shape[0] * asm.nip)
+        asm.set_history(0, hist)
+    ext = model in (capi.PHASE_FRACTURE_EXT, capi.PHASE_FRACTURE_EXTIT)
+    mext = model in (capi.MICRO_PHASE_FRACTURE_EXT, capi.MICRO_PHASE_FRACTURE_EXTIT)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    args = dict(state0=t(st0) if ext else None, state00=t(st00) if (ext or mext) else None, dt=0.7, dt0=0.4)
+    wants_err = model in (capi.PHASE_FRACTURE_EXTIT, capi.MICRO_PHASE_FRACTURE_EXTIT)
+    err = torch.zeros(1, dtype=torch.float64, device=dev) if wants_err else None
+    K = torch.full((asm.nnz,), 9.0, dtype=torch.float64, device=dev); f = torch.full((asm.ndof,), -4.0, dtype=torch.float64, device=dev)
+    asm.assemble(t(st), K, f, err_ext=err, flags=capi.OVERWRITE | capi.STORE_STRAIN, **args)
+    torch.cuda.synchronize()
+    ref = po.assemble(cfg, coords, conn, rp, ci, st, state0=st0 if ext else None, state00=st00 if (ext or mext) else None,
+                      dt=0.7, dt0=0.4, hist_pre=hist, want_strain=True)
+    assert rel_rowmax_err(rp, K.cpu().numpy(), ref["K"]) < 1e-12
+    assert vec_err(f.cpu().numpy(), ref["f"]) < 1e-12
+    assert np.abs(asm.get_strain_cache() - ref["strain"]).max() < 1e-12 * np.abs(ref["strain"]).max()
+    if hist is not None:
+        assert np.abs(asm.get_history(1) - ref["hist_new"]).max() < 1e-12 * max(1.0, np.abs(ref["hist_new"]).max())
+    if wants_err:
+        assert abs(err.item() - ref["err_ext"]) < 1e-12 * ref["err_ext"]
+    # K is bitwise repeatable; += semantics on top of a non-zero matrix; GET_INT_VECTOR pass
+    K2 = torch.zeros_like(K); f2 = torch.zeros_like(f)
+    asm.assemble(t(st), K2, f2, flags=capi.OVERWRITE, **args)
+    assert torch.equal(K, K2)
+    K3 = torch.full_like(K, 2.0); f3 = torch.full_like(f, 1.0)
+    asm.assemble(t(st), K3, f3, flags=capi.ACCUMULATE, **args)
+    f4 = torch.zeros_like(f)
+    asm.assemble(t(st), None, f4, flags=capi.OVERWRITE, **args)
+    torch.cuda.synchronize()
+    kmax = K.abs().max().item(); fmax = f.abs().max().item()
+    assert (K3 - 2.0 - K).abs().max().item() < 1e-12 * kmax and (f3 - 1.0 - f).abs().max().item() < 1e-12 * fmax
+    assert (f4 - f).abs().max().item() < 1e-12 * fmax
