@@ -480,12 +480,10 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
 template <class SH, int FAM, bool WANT_K, bool KEEP, class SP>
 static int launch_tiles_one(const Params& P, int grid, hipStream_t st) {
   auto kern = assemble_tiles<SH, FAM, WANT_K, KEEP, SP>;
-  static size_t configured = 0;                        // per instantiation
   const size_t shmem = (size_t)P.tile_lds;
-  if (shmem > 65536 - 64 && shmem > configured) {
+  if (shmem > 65536 - 64) {                            // per device and per context size: set on every launch (microseconds)
     hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (rc != hipSuccess) return (int)rc;
-    configured = shmem;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kTileBlock), shmem, st, P);
   return (int)hipGetLastError();
