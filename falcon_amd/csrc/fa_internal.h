@@ -55,11 +55,12 @@ enum { FAM_LE = 0, FAM_PF_ISO = 1, FAM_PF_MIEHE = 2 };
 #define FA_TILE_LDS 81856
 #endif
 constexpr int kTileBlock = FA_TILE_BLOCK, kTileLds = FA_TILE_LDS, kTileInfo = 8;
-// doubles of one Gauss-point record: J^-1, w det J, tangent (3 isotropic coefficients or the packed symmetric D),
+// doubles of one Gauss-point record: J^-1, w det J, tangent (3 isotropic coefficients or the packed symmetric D;
+// nothing for Hooke, whose tangent is a constant),
 // c1 for phase-field families, sigma+ / g' / loading g' when the off-diagonal blocks are kept
 constexpr int tile_rec_doubles(int rank, int fam, bool keep) {
   const int S = (rank == 2) ? 3 : 6;
-  return rank * rank + 1 + (fam == FAM_PF_MIEHE ? S * (S + 1) / 2 : 3) + (fam != FAM_LE ? 1 : 0) + (keep ? S + 2 : 0);
+  return rank * rank + 1 + (fam == FAM_PF_MIEHE ? S * (S + 1) / 2 : (fam != FAM_LE ? 3 : 0)) + (fam != FAM_LE ? 1 : 0) + (keep ? S + 2 : 0);
 }
 // doubles of one element slot (nip records): odd, so that lanes reading the same field of different slots spread
 // over the LDS banks

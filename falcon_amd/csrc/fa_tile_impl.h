@@ -33,7 +33,7 @@ template <class SH, int FAM, bool KEEP>
 struct TileRec {                                        // offsets (doubles) inside one Gauss-point record
   static constexpr int R = SH::RANK, S = SH::S;
   static constexpr bool PF = (FAM != FAM_LE), GEN = (FAM == FAM_PF_MIEHE);
-  static constexpr int O_INV = 0, O_W = R * R, O_D = O_W + 1, NDC = GEN ? S * (S + 1) / 2 : 3;
+  static constexpr int O_INV = 0, O_W = R * R, O_D = O_W + 1, NDC = GEN ? S * (S + 1) / 2 : (PF ? 3 : 0);   // Hooke: the tangent is a constant of the launch
   static constexpr int O_C1 = O_D + NDC, O_SP = O_C1 + (PF ? 1 : 0), W = O_SP + (KEEP ? S + 2 : 0);
   static_assert(W == tile_rec_doubles(R, FAM, KEEP), "host and device disagree on the record width");
 };
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
       for (int i = 0; i < S; i++)
 #pragma unroll
         for (int j = i; j < S; j++) rec[TR::O_D + (q++)] = m.D[i][j];
-    } else {
+    } else if constexpr (PF) {
       rec[TR::O_D] = m.d0; rec[TR::O_D + 1] = m.d1; rec[TR::O_D + 2] = m.d3;
     }
     if constexpr (PF) rec[TR::O_C1] = m.c1;
@@ -329,13 +329,13 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
             for (int j = 0; j < RANK; j++) Kuu[i][j] += tt[j];
           }
         } else if constexpr (RANK == 2) {
-          const double d0 = rec[TR::O_D], d1 = rec[TR::O_D + 1], d3 = rec[TR::O_D + 2];
+          const double d0 = PF ? rec[TR::O_D] : P.hd0, d1 = PF ? rec[TR::O_D + 1] : P.hd1, d3 = PF ? rec[TR::O_D + 2] : P.hd3;
           Kuu[0][0] += (wga[0] * d0) * gb[0] + (wga[1] * d3) * gb[1];
           Kuu[0][1] += (wga[0] * d1) * gb[1] + (wga[1] * d3) * gb[0];
           Kuu[1][0] += (wga[1] * d1) * gb[0] + (wga[0] * d3) * gb[1];
           Kuu[1][1] += (wga[1] * d0) * gb[1] + (wga[0] * d3) * gb[0];
         } else {
-          const double d0 = rec[TR::O_D], d1 = rec[TR::O_D + 1], d3 = rec[TR::O_D + 2];
+          const double d0 = PF ? rec[TR::O_D] : P.hd0, d1 = PF ? rec[TR::O_D + 1] : P.hd1, d3 = PF ? rec[TR::O_D + 2] : P.hd3;
           const double dotp = wga[0] * gb[0] + wga[1] * gb[1] + wga[2] * gb[2];
 #pragma unroll
           for (int i = 0; i < 3; i++)
