@@ -52,7 +52,7 @@ class AssembleArgs(C.Structure):
 EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_nip_total", "fa_ndof_per_node",
            "fa_strain_rows", "fa_uses_row_kernel", "fa_psi0", "fa_patch_stats", "fa_pattern_host", "fa_pattern_device",
            "fa_assemble", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
-           "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables"]
+           "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum"]
 
 _lib = None
 
@@ -82,6 +82,7 @@ def lib():
         L.fa_set_history.argtypes = [vp, C.c_int32, vp]
         L.fa_history_device.argtypes = [vp, C.c_int32]; L.fa_history_device.restype = vp
         L.fa_get_strain_cache.argtypes = [vp, vp]
+        L.fa_gather_sum.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
         ip = C.POINTER(C.c_int32)
         L.fa_shape_info.argtypes = [C.c_int32, ip, ip, ip]
         L.fa_shape_tables.argtypes = [C.c_int32, vp, vp, vp]
@@ -189,6 +190,17 @@ class Assembler:
         _check(lib().fa_assemble_host(self.h, _np_ptr(state), _np_ptr(s0), _np_ptr(s00), dt, dt0, _np_ptr(K),
                                       _np_ptr(f), _np_ptr(err) if want_err else None, flags))
         return K, f, float(err[0])
+
+    def gather_sum(self, vec, idx, out=None, stream=None):
+        """sum of vec[idx] (idx < 0 skipped) on the device: LodiModel's load / disp sums (LodiModel.cpp:263-283)."""
+        import torch
+        assert vec.is_cuda and vec.dtype == torch.float64 and idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous()
+        if out is None:
+            out = torch.empty(1, dtype=torch.float64, device=vec.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().fa_gather_sum(self.h, vec.data_ptr(), idx.data_ptr(), idx.numel(), out.data_ptr(), stream))
+        return out
 
     def commit(self):
         _check(lib().fa_commit(self.h))

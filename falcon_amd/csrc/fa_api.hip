@@ -934,6 +934,29 @@ extern "C" fa_status fa_set_history(fa_ctx* c, int32_t which, const double* in) 
   return FA_OK;
 }
 
+// one workgroup, fixed order: strided partial sums per thread, then a tree over the 1024 threads
+__global__ __launch_bounds__(1024) void gather_sum_kernel(const double* __restrict__ vec, const int64_t* __restrict__ idx,
+                                                          int64_t n, double* __restrict__ out) {
+  __shared__ double s[1024];
+  double acc = 0.0;
+  for (int64_t k = threadIdx.x; k < n; k += 1024) { const int64_t i = idx[k]; if (i >= 0) acc += vec[i]; }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = s[0];
+}
+
+extern "C" fa_status fa_gather_sum(fa_ctx* c, const double* vec, const int64_t* idx, int64_t n, double* out, void* stream) {
+  if (!c || !vec || !out || n < 0 || (n > 0 && !idx)) return fail(FA_ERR_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(c->prob.device));
+  hipLaunchKernelGGL(gather_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, vec, idx, n, out);
+  HIP_TRY(hipGetLastError());
+  return FA_OK;
+}
+
 extern "C" double* fa_history_device(fa_ctx* c, int32_t which) {
   return (c && which >= 0 && which <= 1) ? c->d_hist[which] : nullptr;
 }

@@ -159,6 +159,14 @@ double*   fa_history_device(fa_ctx* ctx, int32_t which);
  * made with FA_STORE_STRAIN. */
 fa_status fa_get_strain_cache(const fa_ctx* ctx, double* host_out);
 
+/* Host consumers of f_int / state: LodiModel sums the internal force and the state over the dofs
+ * of a node group on every GET_MATRIX0 / GET_INT_VECTOR (src/io/models/LodiModel.cpp:263-283: load[i] +=
+ * fint1[idofs(i,j)], disp[i] += state[idofs(i,j)], entries < 0 skipped).  With a device-resident f_int that is one
+ * small reduction instead of a copy of the whole vector: out[0] = sum_k vec[idx[k]] over the n device-resident
+ * indices (idx[k] < 0 skipped), summed in a fixed order (bitwise repeatable).  vec, idx, out: device pointers.  The
+ * caller divides by the node count and does the allsum over ranks as LodiModel does (:266,:288-289). */
+fa_status fa_gather_sum(fa_ctx* ctx, const double* vec, const int64_t* idx, int64_t n, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

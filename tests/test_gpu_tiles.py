@@ -82,3 +82,34 @@ def test_tile_kernel_parity_on_many_tiles(case):
     kmax = K.abs().max().item(); fmax = f.abs().max().item()
     assert (K3 - 2.0 - K).abs().max().item() < 1e-12 * kmax and (f3 - 1.0 - f).abs().max().item() < 1e-12 * fmax
     assert (f4 - f).abs().max().item() < 1e-12 * fmax
+
+
+def test_lodi_sums_on_the_device():
+    """LodiModel's load / displacement sums over a node group (LodiModel.cpp:263-283) from the
+    device-resident f_int and state: same value as the serial loop to 1e-12 of sum|terms|, skipped entries (< 0)
+    as in the reference, bitwise repeatable."""
+    import torch
+    coords, conn = meshgen.grid_quad4(60, 40)
+    asm = capi.Assembler(capi.QUAD4_G2, capi.PHASE_FRACTURE, capi.AMOR_PHASE, coords, conn, young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2)
+    dev = torch.device("cuda", 0)
+    st = meshgen.smooth_state(coords, 3, seed=2, amp=5e-3, noise=1e-4, l0=0.3)
+    f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+    asm.assemble(torch.from_numpy(st).to(dev), None, f, flags=capi.OVERWRITE)
+    top = np.nonzero(np.abs(coords[:, 1] - coords[:, 1].max()) < 1e-12)[0]             # node group "top"
+    fh = f.cpu().numpy()
+    for typ in range(2):                                                               # dof types dx, dy
+        idofs = top * 3 + typ
+        idofs[::7] = -1                                                                # dofs that do not exist: skipped
+        load = 0.0; disp = 0.0; scale = 0.0
+        for i in idofs:                                                                # the reference's loop
+            if i >= 0:
+                load += fh[i]; disp += st[i]; scale += abs(fh[i])
+        idx = torch.from_numpy(idofs).to(dev)
+        got = asm.gather_sum(f, idx)
+        got2 = asm.gather_sum(f, idx)
+        gd = asm.gather_sum(torch.from_numpy(st).to(dev), idx)
+        torch.cuda.synchronize()
+        assert abs(got.item() - load) <= 1e-12 * scale and got.item() == got2.item()
+        assert abs(gd.item() - disp) <= 1e-12 * np.abs(st[idofs[idofs >= 0]]).sum()
+    empty = asm.gather_sum(f, torch.zeros(0, dtype=torch.int64, device=dev))
+    assert empty.item() == 0.0
