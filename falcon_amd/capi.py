@@ -52,7 +52,7 @@ class AssembleArgs(C.Structure):
 EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_nip_total", "fa_ndof_per_node",
            "fa_strain_rows", "fa_uses_row_kernel", "fa_psi0", "fa_patch_stats", "fa_pattern_host", "fa_pattern_device",
            "fa_assemble", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
-           "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum"]
+           "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum", "fa_strain_table"]
 
 _lib = None
 
@@ -83,6 +83,7 @@ def lib():
         L.fa_history_device.argtypes = [vp, C.c_int32]; L.fa_history_device.restype = vp
         L.fa_get_strain_cache.argtypes = [vp, vp]
         L.fa_gather_sum.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
+        L.fa_strain_table.argtypes = [vp, vp, vp, vp]
         ip = C.POINTER(C.c_int32)
         L.fa_shape_info.argtypes = [C.c_int32, ip, ip, ip]
         L.fa_shape_tables.argtypes = [C.c_int32, vp, vp, vp]
@@ -190,6 +191,16 @@ class Assembler:
         _check(lib().fa_assemble_host(self.h, _np_ptr(state), _np_ptr(s0), _np_ptr(s00), dt, dt0, _np_ptr(K),
                                       _np_ptr(f), _np_ptr(err) if want_err else None, flags))
         return K, f, float(err[0])
+
+    def strain_table(self, table, weights, stream=None):
+        """getStrain_: table[nnode][str] and weights[nnode] (device tensors) are added to from the strain cache."""
+        import torch
+        assert table.is_cuda and weights.is_cuda and table.dtype == torch.float64 and weights.dtype == torch.float64
+        assert table.is_contiguous() and table.numel() == self.nnode * (self.strain_rows - (0 if self.model == LINEAR_ELASTICITY else 1))
+        assert weights.numel() == self.nnode
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().fa_strain_table(self.h, table.data_ptr(), weights.data_ptr(), stream))
 
     def gather_sum(self, vec, idx, out=None, stream=None):
         """sum of vec[idx] (idx < 0 skipped) on the device: LodiModel's load / disp sums (LodiModel.cpp:263-283)."""

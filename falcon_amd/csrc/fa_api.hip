@@ -934,6 +934,42 @@ extern "C" fa_status fa_set_history(fa_ctx* c, int32_t which, const double* in) 
   return FA_OK;
 }
 
+// getStrain_: one lane per node; per incident element the sum over its Gauss points first, then the add (the order in
+// which the reference's element loop reaches the node)
+__global__ void strain_table_kernel(const int32_t* __restrict__ n2e_ptr, const int32_t* __restrict__ n2e_ent,
+                                    const double* __restrict__ tabN, const double* __restrict__ strain, int srows, int str,
+                                    int npe, int nip, int64_t nnode, double* __restrict__ table, double* __restrict__ weights) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nnode) return;
+  double acc[6] = { 0, 0, 0, 0, 0, 0 }, w = 0.0;
+  for (int32_t t = n2e_ptr[n]; t < n2e_ptr[n + 1]; t++) {
+    const int32_t ent = n2e_ent[t];
+    const int64_t e = ent / npe; const int la = ent - (int32_t)e * npe;
+    double el[6] = { 0, 0, 0, 0, 0, 0 }, ew = 0.0;
+    for (int ip = 0; ip < nip; ip++) {
+      const double N = tabN[ip * npe + la];
+      const double* sp = strain + (e * nip + ip) * srows;
+      for (int c = 0; c < 6; c++) if (c < str) el[c] += N * sp[c];
+      ew += N;
+    }
+    for (int c = 0; c < 6; c++) acc[c] += el[c];
+    w += ew;
+  }
+  for (int c = 0; c < 6; c++) if (c < str) table[n * str + c] += acc[c];
+  weights[n] += w;
+}
+
+extern "C" fa_status fa_strain_table(fa_ctx* c, double* table, double* weights, void* stream) {
+  if (!c || !table || !weights) return fail(FA_ERR_ARG, "null argument");
+  if (!c->d_strain) return fail(FA_ERR_ARG, "no strain cache: assemble with FA_STORE_STRAIN first");
+  HIP_TRY(hipSetDevice(c->prob.device));
+  if (c->nnode == 0) return FA_OK;
+  hipLaunchKernelGGL(strain_table_kernel, dim3((unsigned)((c->nnode + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     c->d_n2e_ptr, c->d_n2e_ent, c->d_tab, c->d_strain, c->srows, c->str, c->npe, c->nip, c->nnode, table, weights);
+  HIP_TRY(hipGetLastError());
+  return FA_OK;
+}
+
 // one workgroup, fixed order: strided partial sums per thread, then a tree over the 1024 threads
 __global__ __launch_bounds__(1024) void gather_sum_kernel(const double* __restrict__ vec, const int64_t* __restrict__ idx,
                                                           int64_t n, double* __restrict__ out) {

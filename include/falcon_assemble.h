@@ -159,6 +159,14 @@ double*   fa_history_device(fa_ctx* ctx, int32_t which);
  * made with FA_STORE_STRAIN. */
 fa_status fa_get_strain_cache(const fa_ctx* ctx, double* host_out);
 
+/* getStrain_ (PhaseFractureModel.cpp:1282-1395): the Gauss-point strains of the strain_ cache are
+ * extrapolated to the nodes with the transposed shape functions: table[node][c] += sum over the node's elements and
+ * their Gauss points of N_node(ip) strain_(c, ipoint), weights[node] += sum N_node(ip) (Jive divides the table rows by
+ * the weights afterwards).  table: device [nnode][str] (str = 4 in 2-D: xx, yy, zz, xy; 6 in 3-D), weights: device
+ * [nnode]; both are added to, like table.addBlock / `select(weights, inodes) +=`.  Needs a strain cache filled by a
+ * call with FA_STORE_STRAIN.  One lane per node, elements ascending: same summation order as the reference's loop. */
+fa_status fa_strain_table(fa_ctx* ctx, double* table, double* weights, void* stream);
+
 /* Host consumers of f_int / state: LodiModel sums the internal force and the state over the dofs
  * of a node group on every GET_MATRIX0 / GET_INT_VECTOR (src/io/models/LodiModel.cpp:263-283: load[i] +=
  * fint1[idofs(i,j)], disp[i] += state[idofs(i,j)], entries < 0 skipped).  With a device-resident f_int that is one

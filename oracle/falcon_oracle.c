@@ -635,6 +635,33 @@ static int material_update_split(const fo_config* cfg, int rank, const double* s
 static __thread int64_t g_micro_stale = 0;
 int64_t fo_micro_stale_hits(void) { return g_micro_stale; }
 
+/* getStrain_ (PhaseFractureModel.cpp:1282-1395; LinearElasticityModel has the same loop): the Gauss-point strains of
+ * the strain_ cache are extrapolated to the nodes with the transposed shape functions, element by element:
+ * ndStrain = sum_ip N(:,ip) strain_(0:str, ipoint), ndWeights = sum_ip N(:,ip); weights[inodes] += ndWeights,
+ * table.addBlock(inodes, jcols, ndStrain) (+=).  strain: [nel*nip][srows] (column ipoint of strain_), table:
+ * [nnode][str], weights: [nnode]; the caller (Jive) divides the rows by the weights afterwards. */
+int fo_strain_table(int shape, int64_t nel, const int32_t* conn, const double* strain, int srows, int str,
+                    double* table, double* weights) {
+  shape_t s;
+  if (shape_init(&s, shape)) return -1;
+  int64_t ipoint = 0;
+  for (int64_t ie = 0; ie < nel; ie++) {
+    double ndStrain[MAXNPE][6], ndWeights[MAXNPE];
+    for (int a = 0; a < s.npe; a++) { ndWeights[a] = 0.0; for (int c = 0; c < str; c++) ndStrain[a][c] = 0.0; }
+    for (int ip = 0; ip < s.nip; ip++, ipoint++)
+      for (int a = 0; a < s.npe; a++) {
+        for (int c = 0; c < str; c++) ndStrain[a][c] += s.N[ip][a] * strain[ipoint * srows + c];
+        ndWeights[a] += s.N[ip][a];
+      }
+    for (int a = 0; a < s.npe; a++) {
+      const int64_t n = conn[ie * s.npe + a];
+      weights[n] += ndWeights[a];
+      for (int c = 0; c < str; c++) table[n * str + c] += ndStrain[a][c];
+    }
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Fracture constants: PhaseFractureModel.cpp:296-355                        */
 /* ------------------------------------------------------------------------- */

@@ -86,6 +86,9 @@ int  fo_ndof_per_node(int model, int rank);
 /* number of Gauss points of the last fo_assemble call (this thread) that took the `d > 1` branch of
  * MicroPhaseFractureModel.cpp:772-776, where the reference uses a dphidStrain left over from an earlier point */
 int64_t fo_micro_stale_hits(void);
+/* getStrain_ (PhaseFractureModel.cpp:1282-1395): nodal sums of the cached Gauss-point strains and of the weights */
+int fo_strain_table(int shape, int64_t nel, const int32_t* conn, const double* strain, int srows, int str,
+                    double* table, double* weights);
 
 /* Psi0 = initial history value, PhaseFractureModel.cpp:296-359 */
 double fo_psi0(const fo_config* cfg);

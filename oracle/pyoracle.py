@@ -65,6 +65,7 @@ def lib():
         L.fo_pattern.restype = C.c_int64
         L.fo_assemble.argtypes = [C.POINTER(Config), C.c_int, dp, C.c_int64, ip32, C.c_int64, C.c_int64,
                                   ip64, ip32, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp]
+        L.fo_strain_table.argtypes = [C.c_int, C.c_int64, ip32, dp, C.c_int, C.c_int, dp, dp]
         L.fo_last_error.restype = C.c_char_p
         _lib = L
     return _lib
@@ -86,6 +87,18 @@ def shape_tables(shape):
     N = np.zeros((nip, npe)); dN = np.zeros((nip, npe, rank)); w = np.zeros(nip)
     lib().fo_shape_tables(shape, _p(N, C.c_double), _p(dN, C.c_double), _p(w, C.c_double))
     return N, dN, w
+
+
+def strain_table(shape, nnode, conn, strain):
+    """getStrain_: (table[nnode][str], weights[nnode]) from the strain_ cache [nip_total][srows]."""
+    rank = shape_info(shape)[0]
+    str_ = 4 if rank == 2 else 6
+    conn = np.ascontiguousarray(conn, dtype=np.int32); strain = np.ascontiguousarray(strain, dtype=np.float64)
+    table = np.zeros((nnode, str_)); weights = np.zeros(nnode)
+    rc = lib().fo_strain_table(shape, conn.shape[0], _p(conn, C.c_int32), _p(strain, C.c_double), strain.shape[1], str_,
+                               _p(table, C.c_double), _p(weights, C.c_double))
+    assert rc == 0
+    return table, weights
 
 
 def ndof_per_node(model, rank):

@@ -113,3 +113,37 @@ def test_lodi_sums_on_the_device():
         assert abs(gd.item() - disp) <= 1e-12 * np.abs(st[idofs[idofs >= 0]]).sum()
     empty = asm.gather_sum(f, torch.zeros(0, dtype=torch.int64, device=dev))
     assert empty.item() == 0.0
+
+
+@pytest.mark.parametrize("shape,mesh,model,material", [
+    (capi.QUAD4_G2, lambda: meshgen.grid_quad4(30, 21), capi.PHASE_FRACTURE, capi.AMOR_PHASE),
+    (capi.HEX8_G2, lambda: meshgen.grid_hex8(7, 6, 5), capi.PHASE_FRACTURE, capi.MIEHE_PHASE),
+    (capi.TRI6_G3, lambda: meshgen.grid_tri6(12, 9), capi.LINEAR_ELASTICITY, capi.HOOKE),
+    (capi.HEX20_G2, lambda: meshgen.grid_hex20(3, 3, 2), capi.LINEAR_ELASTICITY, capi.HOOKE)])
+def test_strain_table_matches_get_strain(shape, mesh, model, material):
+    """getStrain_ (PhaseFractureModel.cpp:1282-1395) from the device-resident strain_ cache: nodal sums and weights to
+    1e-12 of the oracle's element loop, added on top of what the table already holds (addBlock semantics)."""
+    import torch
+    coords, conn = mesh()
+    coords = meshgen.distort(coords, conn, 0.05, 2)
+    coords, conn, _ = meshgen.shuffle_nodes(coords, conn, 9)
+    rank = coords.shape[1]
+    nd = rank + (0 if model == capi.LINEAR_ELASTICITY else 1)
+    kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2)
+    asm = capi.Assembler(shape, model, material, coords, conn, **kw)
+    dev = torch.device("cuda", 0)
+    st = meshgen.smooth_state(coords, nd, seed=2, amp=5e-3, noise=1e-4, l0=0.3)
+    f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+    table = torch.full((asm.nnode, 4 if rank == 2 else 6), 0.5, dtype=torch.float64, device=dev)
+    weights = torch.full((asm.nnode,), 0.25, dtype=torch.float64, device=dev)
+    with pytest.raises(capi.FaError, match="FA_STORE_STRAIN"):
+        asm.strain_table(table, weights)
+    asm.assemble(torch.from_numpy(st).to(dev), None, f, flags=capi.OVERWRITE | capi.STORE_STRAIN)
+    asm.strain_table(table, weights)
+    torch.cuda.synchronize()
+    cfg = po.make_config(shape, model, material, **kw)
+    rp, ci = asm.pattern()
+    ref = po.assemble(cfg, coords, conn, rp, ci, st, want_K=False, want_strain=True)
+    tr, wr = po.strain_table(shape, coords.shape[0], conn, ref["strain"])
+    assert np.abs(table.cpu().numpy() - 0.5 - tr).max() < 1e-12 * np.abs(tr).max()
+    assert np.abs(weights.cpu().numpy() - 0.25 - wr).max() < 1e-12 * np.abs(wr).max()

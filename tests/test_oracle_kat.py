@@ -377,3 +377,30 @@ def test_micro_ext_reduces_to_plain_micro_and_blocks():
     assert r["err_ext"] > 0 and np.all(r["hist_new"] >= plain["hist_new"])
     # errExt_ = sum over Gauss points of (pf - pfEx)^2 = 0.05^2 * number of points (partition of unity)
     assert abs(r["err_ext"] - 0.05 ** 2 * conn.shape[0] * 4) < 1e-12
+
+
+# ---- getStrain_ (PhaseFractureModel.cpp:1282-1395) ----
+@pytest.mark.parametrize("shape,mesh", [(po.QUAD4_G2, lambda: meshgen.grid_quad4(5, 4)), (po.TRI6_G3, lambda: meshgen.grid_tri6(3, 4)),
+                                        (po.HEX8_G2, lambda: meshgen.grid_hex8(3, 2, 2)), (po.HEX20_G3, lambda: meshgen.grid_hex20(2, 2, 1))])
+def test_strain_table_of_a_linear_field(shape, mesh):
+    """A linear displacement field has the same strain at every Gauss point, so a node's table row is that strain times
+    the node's weight; the weights are sum_e sum_ip N_node(ip)."""
+    coords, conn = mesh()
+    coords = meshgen.distort(coords, conn, 0.05)
+    rank = coords.shape[1]
+    rng = np.random.default_rng(3)
+    G = rng.uniform(-1e-3, 1e-3, (rank, rank))
+    u = coords @ G.T
+    cfg = po.make_config(shape, po.LINEAR_ELASTICITY, po.HOOKE, young=100.0, poisson=0.25)
+    rp, ci = po.pattern(coords.shape[0], conn, rank, rank)
+    r = po.assemble(cfg, coords, conn, rp, ci, u.reshape(-1), want_strain=True)
+    table, weights = po.strain_table(shape, coords.shape[0], conn, r["strain"])
+    eps = 0.5 * (G + G.T)
+    exact = [eps[0, 0], eps[1, 1], 0.0, 2 * eps[0, 1]] if rank == 2 else [eps[0, 0], eps[1, 1], eps[2, 2], 2 * eps[0, 1], 2 * eps[1, 2], 2 * eps[0, 2]]
+    # table = strain * weights (not table / weights: with Triangle6 / Gauss3 the corner weights are 2/9 - 1/9 - 1/9 = 0,
+    # in the reference as well)
+    assert np.abs(table - weights[:, None] * np.array(exact)).max() < 1e-14
+    N = po.shape_tables(shape)[0]
+    w_ref = np.zeros(coords.shape[0])
+    np.add.at(w_ref, conn.reshape(-1), np.tile(N.sum(axis=0), conn.shape[0]))
+    assert np.abs(weights - w_ref).max() < 1e-13
