@@ -52,7 +52,7 @@ class AssembleArgs(C.Structure):
 EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_nip_total", "fa_ndof_per_node",
            "fa_strain_rows", "fa_uses_row_kernel", "fa_psi0", "fa_patch_stats", "fa_pattern_host", "fa_pattern_device",
            "fa_assemble", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
-           "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum", "fa_strain_table"]
+           "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum", "fa_strain_table", "fa_stress_table"]
 
 _lib = None
 
@@ -84,6 +84,7 @@ def lib():
         L.fa_get_strain_cache.argtypes = [vp, vp]
         L.fa_gather_sum.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
         L.fa_strain_table.argtypes = [vp, vp, vp, vp]
+        L.fa_stress_table.argtypes = [vp, vp, vp, vp]
         ip = C.POINTER(C.c_int32)
         L.fa_shape_info.argtypes = [C.c_int32, ip, ip, ip]
         L.fa_shape_tables.argtypes = [C.c_int32, vp, vp, vp]
@@ -201,6 +202,15 @@ class Assembler:
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         _check(lib().fa_strain_table(self.h, table.data_ptr(), weights.data_ptr(), stream))
+
+    def stress_table(self, table, weights, stream=None):
+        """getStress_: like strain_table, with the stresses of the material update from the cached strain / degradation."""
+        import torch
+        assert table.is_cuda and weights.is_cuda and table.dtype == torch.float64 and weights.dtype == torch.float64
+        assert table.is_contiguous() and table.numel() == self.nnode * (4 if self.rank == 2 else 6) and weights.numel() == self.nnode
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().fa_stress_table(self.h, table.data_ptr(), weights.data_ptr(), stream))
 
     def gather_sum(self, vec, idx, out=None, stream=None):
         """sum of vec[idx] (idx < 0 skipped) on the device: LodiModel's load / disp sums (LodiModel.cpp:263-283)."""

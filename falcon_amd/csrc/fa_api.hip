@@ -970,6 +970,20 @@ extern "C" fa_status fa_strain_table(fa_ctx* c, double* table, double* weights, 
   return FA_OK;
 }
 
+extern "C" fa_status fa_stress_table(fa_ctx* c, double* table, double* weights, void* stream) {
+  if (!c || !table || !weights) return fail(FA_ERR_ARG, "null argument");
+  if (!c->d_strain) return fail(FA_ERR_ARG, "no strain cache: assemble with FA_STORE_STRAIN first");
+  HIP_TRY(hipSetDevice(c->prob.device));
+  if (c->nnode == 0) return FA_OK;
+  fa::Params P = c->P;
+  P.strain = c->d_strain;
+  const int ps = (c->prob.state == FA_PLANE_STRESS) ? 1 : 0;
+  const int rc = (c->rank == 2) ? fa::launch_stress_table_2d(P, c->npe, c->nip, ps, table, weights, stream)
+                                : fa::launch_stress_table_3d(P, c->npe, c->nip, ps, table, weights, stream);
+  if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return FA_OK;
+}
+
 // one workgroup, fixed order: strided partial sums per thread, then a tree over the 1024 threads
 __global__ __launch_bounds__(1024) void gather_sum_kernel(const double* __restrict__ vec, const int64_t* __restrict__ idx,
                                                           int64_t n, double* __restrict__ out) {

@@ -150,4 +150,8 @@ int launch_quad8_g2(const Params&, int, bool, bool, int, int, void*);
 int launch_hex20_g3(const Params&, int, bool, bool, int, int, void*);
 int launch_hex20_g2(const Params&, int, bool, bool, int, int, void*);
 
+// getStress_ table kernels, one per space dimension (fa_kernels_quad4.hip / fa_kernels_hex8.hip)
+int launch_stress_table_2d(const Params&, int npe, int nip, int plane_stress, double* table, double* weights, void* stream);
+int launch_stress_table_3d(const Params&, int npe, int nip, int plane_stress, double* table, double* weights, void* stream);
+
 }  // namespace fa

@@ -489,6 +489,71 @@ static int launch_tiles_one(const Params& P, int grid, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// getStress_ (PhaseFractureModel.cpp:1165-1271): one lane per node over its incident elements; per Gauss point the
+// material is updated from the cached strain and the cached degradation (row STR of the cache), all STR components
+// (2-D: xx, yy, zz, xy), and N_node(ip) * stress is summed; per element first, then into the node, like the reference.
+template <int RANK>
+__global__ void stress_table_kernel(const Params P, int npe, int nip, int plane_stress, double* __restrict__ table,
+                                    double* __restrict__ weights) {
+  constexpr int S = (RANK == 2) ? 3 : 6, STR = (RANK == 2) ? 4 : 6;
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P.nnode) return;
+  const bool pf = P.model != 0;
+  const int srows = pf ? STR + 1 : STR;
+  double acc[STR], w = 0.0;
+#pragma unroll
+  for (int c = 0; c < STR; c++) acc[c] = 0.0;
+  for (int32_t t = P.n2e_ptr[n]; t < P.n2e_ptr[n + 1]; t++) {
+    const int32_t ent = P.n2e_ent[t];
+    const int64_t e = ent / npe; const int la = ent - (int32_t)e * npe;
+    double el[STR], ew = 0.0;
+#pragma unroll
+    for (int c = 0; c < STR; c++) el[c] = 0.0;
+#pragma unroll 1
+    for (int ip = 0; ip < nip; ip++) {
+      const double N = P.tab[ip * npe + la];
+      const double* sc = P.strain + (e * nip + ip) * srows;
+      double eps[S], sig[S], sp[S], Psi, d0 = 0.0, d1 = 0.0, d3 = 0.0, szz = 0.0;
+      if constexpr (RANK == 2) { eps[0] = sc[0]; eps[1] = sc[1]; eps[2] = sc[3]; }
+      else {
+#pragma unroll
+        for (int c = 0; c < S; c++) eps[c] = sc[c];
+      }
+      const double g = pf ? sc[STR] : 1.0;
+      if (pf && P.material == 3) {
+        double D[S][S];
+        miehe_update<RANK, S>(P, eps, g, D, sig, sp, Psi);
+        if constexpr (RANK == 2) {                       // the zero zz eigenvalue sits in the negative part
+          const double tr = eps[0] + eps[1];
+          szz = (tr < 0.0) ? P.lmda * tr : g * (P.lmda * tr);
+        }
+      } else {
+        iso_update<RANK, S, SpecRuntime>(P, eps, g, d0, d1, d3, sig, sp, Psi);
+        if constexpr (RANK == 2) szz = (P.material != 1 && plane_stress) ? 0.0 : d1 * eps[0] + d1 * eps[1];
+      }
+      if constexpr (RANK == 2) { el[0] += N * sig[0]; el[1] += N * sig[1]; el[2] += N * szz; el[3] += N * sig[2]; }
+      else {
+#pragma unroll
+        for (int c = 0; c < S; c++) el[c] += N * sig[c];
+      }
+      ew += N;
+    }
+#pragma unroll
+    for (int c = 0; c < STR; c++) acc[c] += el[c];
+    w += ew;
+  }
+#pragma unroll
+  for (int c = 0; c < STR; c++) table[n * STR + c] += acc[c];
+  weights[n] += w;
+}
+
+template <int RANK>
+static int launch_stress_table_rank(const Params& P, int npe, int nip, int plane_stress, double* table, double* weights, void* stream) {
+  hipLaunchKernelGGL(stress_table_kernel<RANK>, dim3((unsigned)((P.nnode + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
+                     P, npe, nip, plane_stress, table, weights);
+  return (int)hipGetLastError();
+}
+
 template <class SH>
 static int launch_tiles_shape(const Params& P, int fam, bool want_K, bool keep, int grid, void* stream) {
   hipStream_t st = (hipStream_t)stream;

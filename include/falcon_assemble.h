@@ -166,6 +166,10 @@ fa_status fa_get_strain_cache(const fa_ctx* ctx, double* host_out);
  * [nnode]; both are added to, like table.addBlock / `select(weights, inodes) +=`.  Needs a strain cache filled by a
  * call with FA_STORE_STRAIN.  One lane per node, elements ascending: same summation order as the reference's loop. */
 fa_status fa_strain_table(fa_ctx* ctx, double* table, double* weights, void* stream);
+/* getStress_ (PhaseFractureModel.cpp:1165-1271; LinearElasticityModel's is the same loop with Hooke): like
+ * fa_strain_table, but every Gauss point's stress comes from the material update with the cached strain and the cached
+ * degradation (`update(stressIp, stiff, strainIp, gphiEx, ipoint)`), all str components (2-D: xx, yy, zz, xy). */
+fa_status fa_stress_table(fa_ctx* ctx, double* table, double* weights, void* stream);
 
 /* Host consumers of f_int / state: LodiModel sums the internal force and the state over the dofs
  * of a node group on every GET_MATRIX0 / GET_INT_VECTOR (src/io/models/LodiModel.cpp:263-283: load[i] +=

@@ -662,6 +662,37 @@ int fo_strain_table(int shape, int64_t nel, const int32_t* conn, const double* s
   return 0;
 }
 
+/* getStress_ (PhaseFractureModel.cpp:1165-1271): per Gauss point the material is updated with the cached strain and the
+ * cached degradation strain_(strCount, ipoint) (`update(stressIp, stiff, strainIp, gphiEx, ipoint)`, all strCount
+ * components: 2-D carries zz), and the stresses are extrapolated to the nodes like the strains above.
+ * LinearElasticityModel's getStress_ is the same loop with Hooke's update (no degradation row in the cache). */
+int fo_stress_table(const fo_config* cfg, int64_t nel, const int32_t* conn, const double* strain, int srows,
+                    double* table, double* weights) {
+  shape_t s;
+  if (shape_init(&s, cfg->shape)) return -1;
+  const int str = STRAIN_COUNTS[s.rank];
+  int64_t ipoint = 0;
+  for (int64_t ie = 0; ie < nel; ie++) {
+    double ndStress[MAXNPE][6], ndWeights[MAXNPE];
+    for (int a = 0; a < s.npe; a++) { ndWeights[a] = 0.0; for (int c = 0; c < str; c++) ndStress[a][c] = 0.0; }
+    for (int ip = 0; ip < s.nip; ip++, ipoint++) {
+      double stressIp[MAXSTR], stiff[MAXSTR * MAXSTR], sp[MAXSTR], psi;
+      const double gphi = (srows > str) ? strain[ipoint * srows + str] : 1.0;
+      if (fo_material_update(cfg, s.rank, strain + ipoint * srows, gphi, stressIp, stiff, &psi, sp)) return -1;
+      for (int a = 0; a < s.npe; a++) {
+        for (int c = 0; c < str; c++) ndStress[a][c] += s.N[ip][a] * stressIp[c];
+        ndWeights[a] += s.N[ip][a];
+      }
+    }
+    for (int a = 0; a < s.npe; a++) {
+      const int64_t n = conn[ie * s.npe + a];
+      weights[n] += ndWeights[a];
+      for (int c = 0; c < str; c++) table[n * str + c] += ndStress[a][c];
+    }
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Fracture constants: PhaseFractureModel.cpp:296-355                        */
 /* ------------------------------------------------------------------------- */

@@ -89,6 +89,9 @@ int64_t fo_micro_stale_hits(void);
 /* getStrain_ (PhaseFractureModel.cpp:1282-1395): nodal sums of the cached Gauss-point strains and of the weights */
 int fo_strain_table(int shape, int64_t nel, const int32_t* conn, const double* strain, int srows, int str,
                     double* table, double* weights);
+/* getStress_ (PhaseFractureModel.cpp:1165-1271): material update from the cached strain / degradation, nodal sums */
+int fo_stress_table(const fo_config* cfg, int64_t nel, const int32_t* conn, const double* strain, int srows,
+                    double* table, double* weights);
 
 /* Psi0 = initial history value, PhaseFractureModel.cpp:296-359 */
 double fo_psi0(const fo_config* cfg);

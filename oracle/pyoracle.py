@@ -66,6 +66,7 @@ def lib():
         L.fo_assemble.argtypes = [C.POINTER(Config), C.c_int, dp, C.c_int64, ip32, C.c_int64, C.c_int64,
                                   ip64, ip32, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp]
         L.fo_strain_table.argtypes = [C.c_int, C.c_int64, ip32, dp, C.c_int, C.c_int, dp, dp]
+        L.fo_stress_table.argtypes = [C.POINTER(Config), C.c_int64, ip32, dp, C.c_int, dp, dp]
         L.fo_last_error.restype = C.c_char_p
         _lib = L
     return _lib
@@ -98,6 +99,19 @@ def strain_table(shape, nnode, conn, strain):
     rc = lib().fo_strain_table(shape, conn.shape[0], _p(conn, C.c_int32), _p(strain, C.c_double), strain.shape[1], str_,
                                _p(table, C.c_double), _p(weights, C.c_double))
     assert rc == 0
+    return table, weights
+
+
+def stress_table(cfg, nnode, conn, strain):
+    """getStress_: (table[nnode][str], weights[nnode]) from the strain_ cache [nip_total][srows] (last row = cached g)."""
+    rank = shape_info(cfg.shape)[0]
+    str_ = 4 if rank == 2 else 6
+    conn = np.ascontiguousarray(conn, dtype=np.int32); strain = np.ascontiguousarray(strain, dtype=np.float64)
+    table = np.zeros((nnode, str_)); weights = np.zeros(nnode)
+    rc = lib().fo_stress_table(C.byref(cfg), conn.shape[0], _p(conn, C.c_int32), _p(strain, C.c_double), strain.shape[1],
+                               _p(table, C.c_double), _p(weights, C.c_double))
+    if rc != 0:
+        raise ValueError(lib().fo_last_error().decode())
     return table, weights
 
 

@@ -147,3 +147,48 @@ def test_strain_table_matches_get_strain(shape, mesh, model, material):
     tr, wr = po.strain_table(shape, coords.shape[0], conn, ref["strain"])
     assert np.abs(table.cpu().numpy() - 0.5 - tr).max() < 1e-12 * np.abs(tr).max()
     assert np.abs(weights.cpu().numpy() - 0.25 - wr).max() < 1e-12 * np.abs(wr).max()
+
+
+@pytest.mark.parametrize("shape,mesh,model,material,state", [
+    (capi.QUAD4_G2, lambda: meshgen.grid_quad4(17, 11), capi.PHASE_FRACTURE, capi.AMOR_PHASE, capi.PLANE_STRAIN),
+    (capi.QUAD4_G2, lambda: meshgen.grid_quad4(9, 8), capi.PHASE_FRACTURE_EXT, capi.BOURDIN_PHASE, capi.PLANE_STRESS),
+    (capi.QUAD8_G3, lambda: meshgen.grid_quad8(6, 5), capi.PHASE_FRACTURE, capi.MIEHE_PHASE, capi.PLANE_STRAIN),
+    (capi.TRI3_G1, lambda: meshgen.grid_tri3(8, 7), capi.LINEAR_ELASTICITY, capi.HOOKE, capi.PLANE_STRESS),
+    (capi.TRI6_G3, lambda: meshgen.grid_tri6(5, 6), capi.LINEAR_ELASTICITY, capi.HOOKE, capi.PLANE_STRAIN),
+    (capi.HEX8_G2, lambda: meshgen.grid_hex8(5, 4, 4), capi.PHASE_FRACTURE, capi.MIEHE_PHASE, capi.PLANE_STRAIN),
+    (capi.HEX8_G2, lambda: meshgen.grid_hex8(4, 4, 3), capi.MICRO_PHASE_FRACTURE, capi.BOURDIN_PHASE, capi.PLANE_STRAIN),
+    (capi.HEX20_G3, lambda: meshgen.grid_hex20(2, 3, 2), capi.PHASE_FRACTURE, capi.AMOR_PHASE, capi.PLANE_STRAIN)])
+def test_stress_table_matches_get_stress(shape, mesh, model, material, state):
+    """getStress_ (PhaseFractureModel.cpp:1165-1271): material update from the cached strain and the cached degradation,
+    all components (zz in 2-D), nodal sums and weights to 1e-12 of the oracle's element loop."""
+    import torch
+    coords, conn = mesh()
+    coords = meshgen.distort(coords, conn, 0.05, 2)
+    rank = coords.shape[1]
+    pf = model != capi.LINEAR_ELASTICITY
+    nd = rank + (1 if pf else 0)
+    micro = model >= capi.MICRO_PHASE_FRACTURE
+    kw = dict(state=state, young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2, beta=250.0 if micro else 6500.0)
+    asm = capi.Assembler(shape, model, material, coords, conn, **kw)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    st = meshgen.smooth_state(coords, nd, seed=4, amp=5e-3, noise=1e-4, l0=0.3)
+    st[0::nd] -= 8e-3 * coords[:, 0]                                      # part of the mesh in compression (tr < 0 branches)
+    st0 = st * 0.9; st00 = st * 0.8
+    ext = model == capi.PHASE_FRACTURE_EXT
+    f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+    asm.assemble(t(st), None, f, state0=t(st0) if ext else None, state00=t(st00) if ext else None, dt=0.5, dt0=0.4,
+                 flags=capi.OVERWRITE | capi.STORE_STRAIN)
+    table = torch.zeros((asm.nnode, 4 if rank == 2 else 6), dtype=torch.float64, device=dev)
+    weights = torch.zeros((asm.nnode,), dtype=torch.float64, device=dev)
+    asm.stress_table(table, weights)
+    torch.cuda.synchronize()
+    cfg = po.make_config(shape, model, material, **kw)
+    rp, ci = asm.pattern()
+    ref = po.assemble(cfg, coords, conn, rp, ci, st, state0=st0 if ext else None, state00=st00 if ext else None, dt=0.5, dt0=0.4,
+                      want_K=False, want_strain=True)
+    tr, wr = po.stress_table(cfg, coords.shape[0], conn, ref["strain"])
+    if rank == 2:
+        assert (np.abs(tr[:, 2]).max() == 0.0) == (state == capi.PLANE_STRESS and material in (capi.HOOKE, capi.BOURDIN_PHASE))
+    assert np.abs(table.cpu().numpy() - tr).max() < 1e-12 * np.abs(tr).max()
+    assert np.abs(weights.cpu().numpy() - wr).max() < 1e-12 * np.abs(wr).max()

@@ -404,3 +404,27 @@ def test_strain_table_of_a_linear_field(shape, mesh):
     w_ref = np.zeros(coords.shape[0])
     np.add.at(w_ref, conn.reshape(-1), np.tile(N.sum(axis=0), conn.shape[0]))
     assert np.abs(weights - w_ref).max() < 1e-13
+
+
+def test_stress_table_of_a_linear_elastic_field():
+    """getStress_ with Hooke on a linear displacement field: every node's row is the constant stress times the node's
+    weight; plane strain carries sigma_zz = nu (sigma_xx + sigma_yy), plane stress sigma_zz = 0."""
+    coords, conn = meshgen.grid_quad4(5, 4)
+    coords = meshgen.distort(coords, conn, 0.08)
+    G = np.array([[1.0e-3, 4.0e-4], [-2.0e-4, 6.0e-4]])
+    u = coords @ G.T
+    E, nu = 100.0, 0.25
+    exx, eyy, gxy = G[0, 0], G[1, 1], G[0, 1] + G[1, 0]
+    for state in (po.PLANE_STRAIN, po.PLANE_STRESS):
+        cfg = po.make_config(po.QUAD4_G2, po.LINEAR_ELASTICITY, po.HOOKE, state=state, young=E, poisson=nu)
+        rp, ci = po.pattern(coords.shape[0], conn, 2, 2)
+        r = po.assemble(cfg, coords, conn, rp, ci, u.reshape(-1), want_strain=True)
+        table, weights = po.stress_table(cfg, coords.shape[0], conn, r["strain"])
+        if state == po.PLANE_STRAIN:
+            a = E / ((1 + nu) * (1 - 2 * nu))
+            sxx = a * ((1 - nu) * exx + nu * eyy); syy = a * (nu * exx + (1 - nu) * eyy); szz = nu * (sxx + syy)
+        else:
+            a = E / (1 - nu * nu)
+            sxx = a * (exx + nu * eyy); syy = a * (nu * exx + eyy); szz = 0.0
+        sxy = E / (2 * (1 + nu)) * gxy
+        assert np.abs(table - weights[:, None] * np.array([sxx, syy, szz, sxy])).max() < 1e-13 * abs(sxx)
