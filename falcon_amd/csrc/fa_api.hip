@@ -579,6 +579,12 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     if (ok) {
       lanes_total += thr; tstart.push_back((int32_t)nnode); lane0.push_back(lanes_total);
       const int64_t nt = (int64_t)tstart.size() - 1;
+      std::vector<int32_t> nlane2((size_t)nt);
+      for (int64_t w = 0; w < nt; w++) nlane2[w] = (int32_t)(lane0[w + 1] - lane0[w]);
+      // records padded to one workgroup's worth per tile: a lane's record address depends on blockIdx only, so its
+      // load does not wait for the tile descriptor
+      P.rec_padded = getenv("FA_PAD_REC") ? atoi(getenv("FA_PAD_REC")) : 1;
+      if (P.rec_padded) { for (int64_t w = 0; w <= nt; w++) lane0[w] = w * kBlock; lanes_total = nt * kBlock; }
       lrec2.assign((size_t)(lanes_total + 2) * LS, 0);
       wginfo2.assign((size_t)nt * fa::kWgInfo, 0);
       parallel_for(nt, [&](int64_t wb, int64_t we) {
@@ -594,7 +600,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
           int32_t* wi = wginfo2.data() + w * fa::kWgInfo;
           int64_t lane = lane0[w];
           wi[0] = (int32_t)n0; wi[1] = (int32_t)n1; wi[2] = (int32_t)(uint32_t)(lane & 0xFFFFFFFFLL); wi[7] = (int32_t)(lane >> 32);
-          wi[3] = (int32_t)(lane0[w + 1] - lane0[w]);
+          wi[3] = nlane2[w];
           wi[4] = (int32_t)(uint32_t)(base & 0xFFFFFFFFLL); wi[5] = (int32_t)(base >> 32);
           wi[6] = (int32_t)(h_rp[n1 * nd] - base);
           auto emit = [&](const Ent& en, bool owner, int half, uint32_t wmask) {

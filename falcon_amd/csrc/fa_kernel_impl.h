@@ -1267,6 +1267,13 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
   const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
   if (tile >= P.ntile2) return;
   const int32_t* __restrict__ wi = P.wginfo2 + (int64_t)tile * kWgInfo;
+  constexpr int LS = lrec_stride2(NPE);
+  int32_t rec[LS];
+  if (P.rec_padded) {                                  // one workgroup's worth of records per tile: no wait for the descriptor
+    const int4* __restrict__ rp4 = (const int4*)(P.lrec2 + ((int64_t)tile * kBlock + tid) * LS);
+#pragma unroll
+    for (int q = 0; q < LS / 4; q++) { const int4 v = rp4[q]; rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w; }
+  }
   const int n0 = wi[0], n1 = wi[1], nlane = wi[3];
   const int64_t t0 = ((int64_t)(uint32_t)wi[2]) | ((int64_t)wi[7] << 32);
   const int64_t base = ((int64_t)(uint32_t)wi[4]) | ((int64_t)wi[5] << 32);
@@ -1275,9 +1282,7 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
   double* sK = sKbuf + odd;
   const int nf = (n1 - n0) * NDOF;
   const bool active = tid < nlane;                     // nlane is even: pairs are active together
-  constexpr int LS = lrec_stride2(NPE);
-  int32_t rec[LS];
-  {
+  if (!P.rec_padded) {
     const int4* __restrict__ rp4 = (const int4*)(P.lrec2 + (t0 + (active ? tid : 0)) * LS);
 #pragma unroll
     for (int q = 0; q < LS / 4; q++) { const int4 v = rp4[q]; rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w; }
