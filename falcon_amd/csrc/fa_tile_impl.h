@@ -395,7 +395,8 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
       return b;
     };
     auto emit = [&](int io, int kp, const double (&blk)[NDOF][NDOF]) {
-      if (NDOF == 4 && P.cnt[0] == 4 && P.cnt[3] == 4) {  // full 4x4 block: each row chunk is 32 bytes, 32-byte aligned
+      // full 4x4 block: each row chunk is 32 bytes at a multiple of 32 bytes from K (two 16-byte stores if K itself is aligned)
+      if (NDOF == 4 && P.cnt[0] == 4 && P.cnt[3] == 4 && (reinterpret_cast<uintptr_t>(P.K) & 15) == 0) {
         if constexpr (NDOF == 4) {
           const long long b0 = sRow[io] + (long long)kp * 4, rs = (long long)sDeg[io] * 4;
 #pragma unroll
@@ -445,6 +446,7 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
         } else {
           stg_base[lane] = -1;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int d = lane; d < 64 * ci; d += 64) {
           const int owner = (ci == 3) ? d / 3 : ((ci == 4) ? (d >> 2) : ((ci == 2) ? (d >> 1) : ((ci == 1) ? d : d / ci)));
@@ -454,6 +456,7 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
             P.K[q] = P.overwrite ? stg[d] : P.K[q] + stg[d];
           }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
       continue;

@@ -192,3 +192,25 @@ def test_stress_table_matches_get_stress(shape, mesh, model, material, state):
         assert (np.abs(tr[:, 2]).max() == 0.0) == (state == capi.PLANE_STRESS and material in (capi.HOOKE, capi.BOURDIN_PHASE))
     assert np.abs(table.cpu().numpy() - tr).max() < 1e-12 * np.abs(tr).max()
     assert np.abs(weights.cpu().numpy() - wr).max() < 1e-12 * np.abs(wr).max()
+
+
+@pytest.mark.parametrize("shape,mesh", [(capi.HEX8_G2, lambda: meshgen.grid_hex8(6, 5, 5)), (capi.QUAD4_G2, lambda: meshgen.grid_quad4(20, 17)),
+                                        (capi.TRI6_G3, lambda: meshgen.grid_tri6(9, 8))])
+def test_value_array_that_is_only_8_byte_aligned(shape, mesh):
+    """A caller's K array need not be 16-byte aligned (a slice of a larger allocation): same values as with an aligned one."""
+    import torch
+    coords, conn = mesh()
+    kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2)
+    asm = capi.Assembler(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, coords, conn, **kw)
+    dev = torch.device("cuda", 0)
+    st = torch.from_numpy(meshgen.smooth_state(coords, asm.ndofpn, seed=2, amp=5e-3, noise=1e-4, l0=0.3)).to(dev)
+    K = torch.zeros(asm.nnz, dtype=torch.float64, device=dev); f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+    asm.assemble(st, K, f, flags=capi.OVERWRITE)
+    big = torch.full((asm.nnz + 3,), 5.0, dtype=torch.float64, device=dev)
+    Ko = big[1:1 + asm.nnz]
+    assert Ko.data_ptr() % 16 == 8
+    f2 = torch.zeros_like(f)
+    asm.assemble(st, Ko, f2, flags=capi.OVERWRITE)
+    torch.cuda.synchronize()
+    assert (Ko - K).abs().max().item() <= 1e-13 * K.abs().max().item()
+    assert big[0].item() == 5.0 and big[-1].item() == 5.0 and big[-2].item() == 5.0      # nothing written outside
