@@ -670,13 +670,19 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       const bool tri = p->shape == FA_TRI3_G1 || p->shape == FA_TRI3_G3 || p->shape == FA_TRI6_G3;
       const bool row_order = getenv("FA_TILE_ORDER") ? atoi(getenv("FA_TILE_ORDER")) != 0 : tri;
       P.tile_stage = row_order ? 1 : 0;
+      // geometry: two 512-thread workgroups per CU with 80 KB each; element slots of >= kTileBigSlot doubles (27-point
+      // Hex20, general tangents in 3-D) get one 1024-thread workgroup with the whole LDS (Hex20 Gauss3^3 at 64^3: 8.8
+      // against 10.9 ms)
+      const int recw = fa::tile_rec_doubles(rank, c->fam, keepK);
+      const bool big = rank == 3 && fa::tile_slot_doubles(sh.nip, recw) >= fa::kTileBigSlot;
+      P.tile_block = big ? fa::kTileBlockBig : fa::kTileBlock;
       c->tile_path = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
-                                     nb_ptr.data(), nb.data(), fa::tile_rec_doubles(rank, c->fam, keepK),
-                                     fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0), fa::kTileLds, row_order, ts);
+                                     nb_ptr.data(), nb.data(), recw, fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0),
+                                     big ? fa::kTileLdsBig : fa::kTileLds, P.tile_block, row_order, ts);
       if (c->tile_path) { c->ntile3 = ts.ntile; P.ntile3 = ts.ntile; P.tile_lds = ts.lds_bytes; }
       // GET_INT_VECTOR passes keep no records, so a tile set sized for GET_MATRIX0 pays its Gauss-point redundancy for
       // nothing: measured faster than the row / cooperative kernels up to ~3 evaluations per point (Hex20 Gauss3: 5)
-      c->tile_force_only = c->tile_path && (env ? true : ts.point_redundancy < 3.0);
+      c->tile_force_only = c->tile_path && (env ? true : (ts.point_redundancy < 3.0 && !big));   // big geometry: one workgroup per CU, 1.1 against 0.67 ms for Hex20
       if (getenv("FA_VERBOSE"))
         fprintf(stderr, "[falcon_assemble] tiles: %s, %d tiles, %.1f owned nodes / %.1f elements per tile, LDS <= %d bytes, "
                 "Gauss-point redundancy %.3f\n", c->tile_path ? "ok" : "not built", ts.ntile,

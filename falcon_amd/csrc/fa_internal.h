@@ -55,6 +55,9 @@ enum { FAM_LE = 0, FAM_PF_ISO = 1, FAM_PF_MIEHE = 2 };
 #define FA_TILE_LDS 81856
 #endif
 constexpr int kTileBlock = FA_TILE_BLOCK, kTileLds = FA_TILE_LDS, kTileInfo = 8;
+// second geometry for element slots too large for a good 80 KB tile (27-point Hex20, general tangents in 3-D): one
+// 1024-thread workgroup per CU with (almost) all of its LDS
+constexpr int kTileBlockBig = 1024, kTileLdsBig = 163000, kTileBigSlot = 200;
 // doubles of one Gauss-point record: J^-1, w det J, tangent (3 isotropic coefficients or the packed symmetric D;
 // nothing for Hooke, whose tangent is a constant),
 // c1 for phase-field families, sigma+ / g' / loading g' when the off-diagonal blocks are kept
@@ -66,7 +69,7 @@ constexpr int tile_rec_doubles(int rank, int fam, bool keep) {
 // over the LDS banks
 constexpr int tile_slot_doubles(int nip, int rec_doubles) { return (nip * rec_doubles) | 1; }
 // bytes of the wave-private staging rows of the row-ordered write-out (64 chunks of a row + 64 row bases per wave)
-constexpr int tile_stage_bytes(int ndofpn) { return (kTileBlock / 64) * (64 * ndofpn + 64) * 8; }
+constexpr int tile_stage_bytes(int ndofpn, int block) { return (block / 64) * (64 * ndofpn + 64) * 8; }
 // doubles staged per tile node: x, u and (phase-field families) phi; the Ext variants add phi of state0 and of
 // state00 / stateExt_ in an array of their own
 constexpr int tile_node_doubles(int rank, bool pf) { return 2 * rank + (pf ? 1 : 0); }
@@ -127,7 +130,7 @@ struct Params {
   double*        f;
   // ---- sizes / switches ----
   int64_t nnode, nel;
-  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2, ntile3, tile_lds, tile_stage, rec_padded;
+  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2, ntile3, tile_lds, tile_stage, tile_block, rec_padded;
   int32_t cnt[4];            // entries per neighbour node in a row of dof type i
   int32_t off[4][4];         // offset of column type j inside that group, -1 if not in the pattern
   // ---- constants ----

@@ -38,9 +38,9 @@ struct TileRec {                                        // offsets (doubles) ins
   static_assert(W == tile_rec_doubles(R, FAM, KEEP), "host and device disagree on the record width");
 };
 
-template <class SH, int FAM, bool WANT_K, bool KEEP, class SP>
-__global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
-  constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, S = SH::S, STR = SH::STR, BLK = kTileBlock;
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP, int BLK>
+__global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
+  constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, S = SH::S, STR = SH::STR;
   constexpr bool PF = (FAM != FAM_LE);
   constexpr int NDOF = PF ? RANK + 1 : RANK;
   using TR = TileRec<SH, FAM, KEEP>;
@@ -480,16 +480,25 @@ __global__ __launch_bounds__(kTileBlock) void assemble_tiles(const Params P) {
   if (PF && P.err_part != nullptr) reduce_err<BLK>(err_acc, sErr, &P.err_part[tile]);
 }
 
-template <class SH, int FAM, bool WANT_K, bool KEEP, class SP>
-static int launch_tiles_one(const Params& P, int grid, hipStream_t st) {
-  auto kern = assemble_tiles<SH, FAM, WANT_K, KEEP, SP>;
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP, int BLK>
+static int launch_tiles_geom(const Params& P, int grid, hipStream_t st) {
+  auto kern = assemble_tiles<SH, FAM, WANT_K, KEEP, SP, BLK>;
   const size_t shmem = (size_t)P.tile_lds;
   if (shmem > 65536 - 64) {                            // per device and per context size: set on every launch (microseconds)
     hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (rc != hipSuccess) return (int)rc;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kTileBlock), shmem, st, P);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(BLK), shmem, st, P);
   return (int)hipGetLastError();
+}
+
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP>
+static int launch_tiles_one(const Params& P, int grid, hipStream_t st) {
+  if constexpr (SH::RANK == 3) {                       // the big geometry exists for the 3-D shapes only
+    if (P.tile_block == kTileBlockBig) return launch_tiles_geom<SH, FAM, WANT_K, KEEP, SP, kTileBlockBig>(P, grid, st);
+  }
+  if (P.tile_block != kTileBlock) return -1000;
+  return launch_tiles_geom<SH, FAM, WANT_K, KEEP, SP, kTileBlock>(P, grid, st);
 }
 
 // getStress_ (PhaseFractureModel.cpp:1165-1271): one lane per node over its incident elements; per Gauss point the

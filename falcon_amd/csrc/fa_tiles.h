@@ -21,12 +21,12 @@ struct TileSet {
 
 // Nodes are sorted along a Morton curve of their grid-quantised coordinates and cut into tiles whose staged data
 // (Gauss-point records of `rec_doubles` each, `node_doubles` per node, f image, shape tables, local connectivity)
-// fit `lds_budget` bytes.  nb_ptr / nb: sorted neighbour lists of the nodes (the column blocks of a node's rows).
+// fit `lds_budget` bytes (`block` = threads of the workgroup that will run a tile: it sizes the staging rows).  nb_ptr / nb: sorted neighbour lists of the nodes (the column blocks of a node's rows).
 // row_order: pair lanes in (node, neighbour) order (coalesced row chunks; for the 3-wide blocks that cannot use
 // 32-byte stores) instead of sorted by element count with (a,b)/(b,a) sharing a lane.
 // Returns false when the mesh cannot be tiled (a single node's elements exceed the budget, counters overflow).
 bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndofpn, const double* coords,
                  const int32_t* conn, const int32_t* n2e_ptr, const int32_t* n2e_ent, const int64_t* nb_ptr,
-                 const int32_t* nb, int rec_doubles, int node_doubles, int lds_budget, bool row_order, TileSet& out);
+                 const int32_t* nb, int rec_doubles, int node_doubles, int lds_budget, int block, bool row_order, TileSet& out);
 
 }  // namespace fa

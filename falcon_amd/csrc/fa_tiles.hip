@@ -111,7 +111,7 @@ struct Cutter {                                        // greedy cut of the sort
 
 bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndofpn, const double* coords,
                  const int32_t* conn, const int32_t* n2e_ptr, const int32_t* n2e_ent, const int64_t* nb_ptr,
-                 const int32_t* nb, int rec_doubles, int node_doubles, int lds_budget, bool row_order, TileSet& T) {
+                 const int32_t* nb, int rec_doubles, int node_doubles, int lds_budget, int block, bool row_order, TileSet& T) {
   if (nnode <= 0 || nel <= 0 || npe > 255) return false;
   // ---- spatial order: Morton code of the coordinates quantised to the mean node spacing ----
   double lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
@@ -145,7 +145,7 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
   code.clear(); code.shrink_to_fit();
 
   const int tabn = nip * npe * (1 + rank) + nip;
-  Cutter C{ nnode, nel, npe, nip, ndofpn, rec_doubles, node_doubles, lds_budget, tabn, row_order ? tile_stage_bytes(ndofpn) : 0, conn, n2e_ptr, n2e_ent, nb_ptr, order, key, {}, {} };
+  Cutter C{ nnode, nel, npe, nip, ndofpn, rec_doubles, node_doubles, lds_budget, tabn, row_order ? tile_stage_bytes(ndofpn, block) : 0, conn, n2e_ptr, n2e_ent, nb_ptr, order, key, {}, {} };
   // ---- cell size: the Morton cell (or none: tiles filled to the budget) that evaluates the fewest elements per owned node ----
   std::vector<int64_t> starts; int64_t by_limit = 0;
   const int64_t sample = std::min<int64_t>(nnode, 200000);

@@ -1,5 +1,5 @@
 // Host-side check of the tile builder (falcon_amd/csrc/fa_tiles.hip, compiled as plain C++ by tests/test_tile_builder.py).
-// usage: tile_builder_check RANK N ROW_ORDER REC_DOUBLES   -> prints "key value" lines, exit code 0 when every invariant holds
+// usage: tile_builder_check RANK N ROW_ORDER REC_DOUBLES BIG   -> prints "key value" lines, exit code 0 when every invariant holds
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -16,6 +16,8 @@ int main(int argc, char** argv) {
   const bool row_order = argc > 3 && atoi(argv[3]) != 0;
   const int npe = rank == 3 ? 8 : 4, nip = npe, nd = rank + 1;
   const int rec = argc > 4 ? atoi(argv[4]) : fa::tile_rec_doubles(rank, fa::FAM_PF_ISO, false);
+  const bool big = argc > 5 && atoi(argv[5]) != 0;           // the 1024-thread / whole-LDS geometry
+  const int budget = big ? fa::kTileLdsBig : fa::kTileLds;
   const int m = n + 1;
   const int64_t nn = rank == 3 ? (int64_t)m * m * m : (int64_t)m * m, nel = rank == 3 ? (int64_t)n * n * n : (int64_t)n * n;
   std::vector<double> x(nn * rank);
@@ -45,7 +47,7 @@ int main(int argc, char** argv) {
   }
   fa::TileSet T;
   const bool ok = fa::build_tiles(nn, nel, npe, nip, rank, nd, x.data(), conn.data(), n2e_ptr.data(), n2e_ent.data(), nb_ptr.data(),
-                                  nb.data(), rec, fa::tile_node_doubles(rank, true), fa::kTileLds, row_order, T);
+                                  nb.data(), rec, fa::tile_node_doubles(rank, true), budget, big ? fa::kTileBlockBig : fa::kTileBlock, row_order, T);
   printf("built %d\n", ok ? 1 : 0);
   if (!ok) return 2;
   std::vector<int> owned(nn, 0), ewr(nel, 0), eseen(nel, 0), blocks(nb.size(), 0);
@@ -100,8 +102,8 @@ int main(int argc, char** argv) {
   for (int v : blocks) blk1 += (v == 1);
   printf("ntile %d\nlds_bytes %d\nlds_budget %d\nredundancy %.4f\nnodes %lld\nowned_once %lld\nelements %lld\nelements_written_once %lld\n"
          "elements_covered %lld\nblocks %zu\nblocks_written_once %lld\nlanes %lld\nmirrored %lld\nbad %lld\ntile_elements %lld\n",
-         T.ntile, T.lds_bytes, fa::kTileLds, T.point_redundancy, (long long)nn, (long long)own1, (long long)nel, (long long)ewr1,
+         T.ntile, T.lds_bytes, budget, T.point_redundancy, (long long)nn, (long long)own1, (long long)nel, (long long)ewr1,
          (long long)ecov, blocks.size(), (long long)blk1, (long long)nlanes, (long long)nmirror, (long long)bad, (long long)tel);
-  const bool good = own1 == nn && ewr1 == nel && ecov == nel && blk1 == (int64_t)blocks.size() && bad == 0 && T.lds_bytes <= fa::kTileLds;
+  const bool good = own1 == nn && ewr1 == nel && ecov == nel && blk1 == (int64_t)blocks.size() && bad == 0 && T.lds_bytes <= budget;
   return good ? 0 : 1;
 }

@@ -50,3 +50,6 @@ def test_tiles_are_compact_on_a_structured_hex8_mesh(checker):
 def test_large_records_shrink_the_tiles_but_stay_valid(checker):
     v = run(checker, 3, 16, 0, 120)          # records as large as a 27-point general-tangent element's
     assert v["bad"] == 0 and v["blocks_written_once"] == v["blocks"] and v["lds_bytes"] <= v["lds_budget"]
+    w = run(checker, 3, 16, 0, 120, 1)       # the same in the whole-LDS geometry: larger tiles, fewer evaluations per point
+    assert w["bad"] == 0 and w["blocks_written_once"] == w["blocks"] and w["lds_bytes"] <= w["lds_budget"]
+    assert w["redundancy"] < v["redundancy"] and w["lds_budget"] > v["lds_budget"]
