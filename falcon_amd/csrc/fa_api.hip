@@ -674,7 +674,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       // Hex20, general tangents in 3-D) get one 1024-thread workgroup with the whole LDS (Hex20 Gauss3^3 at 64^3: 8.8
       // against 10.9 ms)
       const int recw = fa::tile_rec_doubles(rank, c->fam, keepK);
-      const bool big = rank == 3 && fa::tile_slot_doubles(sh.nip, recw) >= fa::kTileBigSlot;
+      const bool big = rank == 3 && (getenv("FA_TILE_BIG") ? atoi(getenv("FA_TILE_BIG")) != 0 : fa::tile_slot_doubles(sh.nip, recw) >= fa::kTileBigSlot);
       P.tile_block = big ? fa::kTileBlockBig : fa::kTileBlock;
       c->tile_path = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
                                      nb_ptr.data(), nb.data(), recw, fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0),
