@@ -64,11 +64,13 @@ def workload(name, n, capi, material="amor", keep=False):
         return dict(desc=f"cfg5: {n}^3 hex20 linear-elastic block (Hooke), Gauss{'3' if g3 else '2'}^3",
                     shape=capi.HEX20_G3 if g3 else capi.HEX20_G2, model=capi.LINEAR_ELASTICITY, material=capi.HOOKE,
                     dims=(n, n, n), h=1.0 / n, written_per_pair=9, kw=dict(young=210e3, poisson=0.3))
-    if name in ("quad8", "quad8g2", "tri6"):   # higher-order 2-D shapes, phase-field fracture like cfg3
+    if name in ("quad8", "quad8g2", "tri6", "tri3", "tri3g3"):   # higher-order 2-D shapes, phase-field fracture like cfg3
         n = n or 1000
         shape, gen, sname = {"quad8": (capi.QUAD8_G3, "grid_quad8", "Quad8 Gauss3*Gauss3"),
                              "quad8g2": (capi.QUAD8_G2, "grid_quad8", "Quad8 Gauss2*Gauss2"),
-                             "tri6": (capi.TRI6_G3, "grid_tri6", "Triangle6 Gauss3")}[name]
+                             "tri6": (capi.TRI6_G3, "grid_tri6", "Triangle6 Gauss3"),
+                             "tri3": (capi.TRI3_G1, "grid_tri3", "Triangle3 Gauss1"),
+                             "tri3g3": (capi.TRI3_G3, "grid_tri3", "Triangle3 Gauss3")}[name]
         return dict(desc=f"{name}: {n}x{n} {sname}, phase-field fracture (u-phi), AT2, {mname}, "
                          f"keepOffDiags={'true' if keep else 'false'}", shape=shape, model=capi.PHASE_FRACTURE,
                     material=mat, dims=(n, n), h=1.0 / n, written_per_pair=9 if keep else 5, gen=gen,
