@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -35,6 +36,47 @@ fa_status fail(fa_status code, const char* fmt, ...) {
 #define HIP_TRY(expr)                                                                              \
   do { hipError_t _e = (expr);                                                                     \
        if (_e != hipSuccess) return fail(FA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } while (0)
+
+// Debug / experiment switches.  They are read from the environment ONCE PER fa_create (so a test can build contexts
+// on different kernel paths in one process) and nowhere else; the defaults are the measured best.  Documented in
+// INTEGRATION.md ("Environment switches").
+struct DebugOptions {
+  int  tiles = -1;        // FA_TILES=0|1: tile kernel off / on for every shape (-1: per-shape default)
+  int  tile_order = -1;   // FA_TILE_ORDER=0|1: pair lanes count-sorted with shared (a,b)/(b,a) lanes | row order
+  int  tile_big = -1;     // FA_TILE_BIG=0|1: two 512-thread workgroups per CU | one of 1024 threads
+  int  emat = -1;         // FA_EMAT=0|1: element-matrix tile kernel (Quad4 / Triangle3) off / on
+  int  emat_nodes = 0;    // FA_EMAT_NODES=n: owned nodes per element-matrix tile (0: default)
+  bool no_pair = false;   // FA_NO_PAIR=1: no lane pairs for Quad4
+  bool pair_3d = false;   // FA_PAIR_3D=1: lane pairs for Hex8 as well
+  int  pad_rec = 1;       // FA_PAD_REC=0: lane records not padded per tile
+  bool use_patch = false; // FA_USE_PATCH=1: experimental patch kernel
+  int  patch_lds = 0;     // FA_PATCH_LDS=n: doubles of LDS for its CSR image
+  bool verbose = false;   // FA_VERBOSE=1: tiling statistics on stderr
+  static DebugOptions from_env() {
+    DebugOptions o;
+    auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1);
+    o.emat = geti("FA_EMAT", -1); o.emat_nodes = geti("FA_EMAT_NODES", 0);
+    o.no_pair = getenv("FA_NO_PAIR") != nullptr; o.pair_3d = getenv("FA_PAIR_3D") != nullptr;
+    o.pad_rec = geti("FA_PAD_REC", 1); o.use_patch = getenv("FA_USE_PATCH") != nullptr;
+    o.patch_lds = geti("FA_PATCH_LDS", 0); o.verbose = getenv("FA_VERBOSE") != nullptr;
+    return o;
+  }
+};
+
+// The entry points run on the context's device and leave the caller's current device as they found it.
+struct DeviceGuard {
+  int prev = -1; bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (prev == dev) || hipSetDevice(dev) == hipSuccess;
+    if (prev == dev) prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define FA_ON_DEVICE(dev)                                                                          \
+  DeviceGuard _guard(dev);                                                                         \
+  if (!_guard.ok) return fail(FA_ERR_HIP, "hipSetDevice(%d) failed", (int)(dev))
 
 template <class F>
 void parallel_for(int64_t n, F&& body) {
@@ -273,13 +315,15 @@ struct fa_ctx {
   // staging for fa_assemble_host
   double *s_state = nullptr, *s_state0 = nullptr, *s_state00 = nullptr, *s_K = nullptr, *s_f = nullptr, *s_err = nullptr;
   std::vector<double> h_tmp;
+  DebugOptions dbg;
+  hipStream_t last_stream = nullptr;   // stream of the last fa_assemble: the host getters / setters wait for it
 };
 
 extern "C" const char* fa_last_error(void) { return g_err.c_str(); }
 
 extern "C" void fa_destroy(fa_ctx* c) {
   if (!c) return;
-  (void)hipSetDevice(c->prob.device);
+  DeviceGuard guard(c->prob.device);
   void* ptrs[] = { c->d_conn, c->d_coords, c->d_row_ptr, c->d_col_idx, c->d_node_dofs, c->d_n2e_ptr, c->d_n2e_ent,
                    c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part,
                    c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err,
@@ -291,6 +335,8 @@ extern "C" void fa_destroy(fa_ctx* c) {
 
 static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   c->prob = *p;
+  c->dbg = DebugOptions::from_env();
+  const DebugOptions& dbg = c->dbg;
   ShapeTab sh;
   if (!make_shape(p->shape, sh))
     return fail(FA_ERR_ARG, "unknown shape id %d", p->shape);
@@ -377,7 +423,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   std::vector<int64_t> nb_ptr(nnode + 1, 0);
   {
     std::vector<int32_t> cnt(nnode, 0);
-    bool overflow = false;
+    std::atomic<bool> overflow{false};
     parallel_for(nnode, [&](int64_t b, int64_t e) {
       std::vector<int32_t> tmp;
       for (int64_t n = b; n < e; n++) {
@@ -388,10 +434,10 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
         }
         std::sort(tmp.begin(), tmp.end());
         cnt[n] = (int32_t)(std::unique(tmp.begin(), tmp.end()) - tmp.begin());
-        if (cnt[n] > 255) overflow = true;
+        if (cnt[n] > 255) overflow.store(true, std::memory_order_relaxed);
       }
     });
-    if (overflow) return fail(FA_ERR_UNSUPPORTED, "a node has more than 255 neighbours");
+    if (overflow.load()) return fail(FA_ERR_UNSUPPORTED, "a node has more than 255 neighbours");
     for (int64_t n = 0; n < nnode; n++) nb_ptr[n + 1] = nb_ptr[n] + cnt[n];
   }
   std::vector<int32_t> nb((size_t)nb_ptr[nnode]);
@@ -451,10 +497,16 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   std::vector<int64_t> rp; std::vector<int32_t> ci;
   int cnt[4] = { 0, 0, 0, 0 }, off[4][4] = { { 0 } };
   bool canonical_dofs = true;
-  if (p->node_dofs) {
-    for (int64_t k = 0; k < nnode * nd && canonical_dofs; k++) canonical_dofs = (p->node_dofs[k] == k);
-  }
   c->ndof = p->ndof > 0 ? p->ndof : nnode * nd;
+  if (p->node_dofs) {
+    for (int64_t k = 0; k < nnode * nd; k++) {
+      if (p->node_dofs[k] < 0 || p->node_dofs[k] >= c->ndof)
+        return fail(FA_ERR_ARG, "node_dofs[%lld] = %lld is outside [0, %lld)", (long long)k, (long long)p->node_dofs[k], (long long)c->ndof);
+      if (p->node_dofs[k] != k) canonical_dofs = false;
+    }
+  } else if (c->ndof < nnode * nd) {
+    return fail(FA_ERR_ARG, "ndof = %lld is smaller than nnode * dofs per node = %lld", (long long)c->ndof, (long long)(nnode * nd));
+  }
   const int64_t* h_rp = nullptr; const int32_t* h_ci = nullptr;
   bool rows_ok = canonical_dofs && (c->ndof == nnode * nd);
   bool col_sorted = true;
@@ -467,7 +519,18 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   } else {
     if (!p->col_idx) return fail(FA_ERR_ARG, "row_ptr given without col_idx");
     h_rp = p->row_ptr; h_ci = p->col_idx;
+    // the caller's arrays are not trusted: offsets start at 0 and never decrease, columns and dofs are in range
+    if (h_rp[0] != 0) return fail(FA_ERR_ARG, "row_ptr[0] is %lld, not 0", (long long)h_rp[0]);
+    for (int64_t r = 0; r < c->ndof; r++)
+      if (h_rp[r + 1] < h_rp[r]) return fail(FA_ERR_ARG, "row_ptr decreases at row %lld", (long long)r);
     const int64_t nnz = h_rp[c->ndof];
+    {
+      std::atomic<int64_t> bad{-1};
+      parallel_for(nnz, [&](int64_t b, int64_t e) {
+        for (int64_t k = b; k < e; k++) if (h_ci[k] < 0 || h_ci[k] >= c->ndof) { bad.store(k, std::memory_order_relaxed); return; }
+      });
+      if (bad.load() >= 0) return fail(FA_ERR_ARG, "col_idx[%lld] = %d is outside [0, %lld)", (long long)bad.load(), h_ci[bad.load()], (long long)c->ndof);
+    }
     if (rows_ok) {                       // is it one of the canonical blocked layouts?
       rows_ok = false;
       for (int kind = 0; kind < 2 && !rows_ok; kind++) {
@@ -480,6 +543,30 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     if (!rows_ok) {
       for (int64_t r = 0; r < c->ndof && col_sorted; r++)
         for (int64_t k = h_rp[r] + 1; k < h_rp[r + 1]; k++) if (h_ci[k - 1] >= h_ci[k]) { col_sorted = false; break; }
+      // Every entry the model writes (MatrixBuilder::addBlock of K1, K4 and, per keepOffDiags / model, K2 and K3:
+      // PhaseFractureModel.cpp:736-746) must exist in the caller's pattern: a missing one is an error here, so that
+      // the scatter kernels never have anything to drop (the reference's builder would add the entry or throw).
+      std::atomic<int64_t> miss_row{-1}, miss_col{-1};
+      auto dofof = [&](int64_t n, int i) -> int64_t { return p->node_dofs ? p->node_dofs[n * nd + i] : n * nd + i; };
+      parallel_for(nnode, [&](int64_t b, int64_t e) {
+        for (int64_t n = b; n < e && miss_row.load(std::memory_order_relaxed) < 0; n++)
+          for (int i = 0; i < nd; i++) {
+            const int64_t row = dofof(n, i);
+            const int32_t* lo = h_ci + h_rp[row]; const int32_t* hi = h_ci + h_rp[row + 1];
+            for (int64_t k = nb_ptr[n]; k < nb_ptr[n + 1]; k++)
+              for (int j = 0; j < nd; j++) {
+                const bool iu = i < rank, ju = j < rank;
+                const bool written = (iu && ju) || (!iu && !ju) || (iu && !ju && P.keep2) || (!iu && ju && P.keep3);
+                if (!written) continue;
+                const int64_t col = dofof(nb[k], j);
+                const bool found = col_sorted ? std::binary_search(lo, hi, (int32_t)col) : (std::find(lo, hi, (int32_t)col) != hi);
+                if (!found) { miss_row.store(row, std::memory_order_relaxed); miss_col.store(col, std::memory_order_relaxed); return; }
+              }
+          }
+      });
+      if (miss_row.load() >= 0)
+        return fail(FA_ERR_ARG, "the CSR pattern has no entry (%lld, %lld), which the model writes (a half-stored / symmetric "
+                    "pattern is not supported: pass the full structure)", (long long)miss_row.load(), (long long)miss_col.load());
     }
   }
   c->nnz = h_rp[c->ndof];
@@ -543,7 +630,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   }
   // ---- pair tiling (row kernel with Gauss points shared by lane pairs; Quad4 / Hex8) ----
   std::vector<int32_t> lrec2, wginfo2;
-  if (rows_ok && nel > 0 && sh.nip % 2 == 0 && (rank == 2 || getenv("FA_PAIR_3D")) && !getenv("FA_NO_PAIR")) {   // Hex8: the pair kernel needs > 512 registers, slower
+  if (rows_ok && nel > 0 && sh.nip % 2 == 0 && (rank == 2 || dbg.pair_3d) && !dbg.no_pair) {   // Hex8: the pair kernel needs > 512 registers, slower
     const int LS = fa::lrec_stride2(npe), HALF = sh.nip / 2;
     // greedy tiles: an element with k nodes in the tile takes 2*ceil(k/2) lanes
     std::vector<int32_t> stamp(nel, -1), cnt_in(nel, 0), tstart;
@@ -583,7 +670,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       for (int64_t w = 0; w < nt; w++) nlane2[w] = (int32_t)(lane0[w + 1] - lane0[w]);
       // records padded to one workgroup's worth per tile: a lane's record address depends on blockIdx only, so its
       // load does not wait for the tile descriptor
-      P.rec_padded = getenv("FA_PAD_REC") ? atoi(getenv("FA_PAD_REC")) : 1;
+      P.rec_padded = dbg.pad_rec;
       if (P.rec_padded) { for (int64_t w = 0; w <= nt; w++) lane0[w] = w * kBlock; lanes_total = nt * kBlock; }
       lrec2.assign((size_t)(lanes_total + 2) * LS, 0);
       wginfo2.assign((size_t)nt * fa::kWgInfo, 0);
@@ -640,15 +727,15 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   }
   // ---- node patches (patch kernel) ----
   fa::PatchSet ps;
-  if (rows_ok && nel > 0 && c->fam != fa::FAM_PF_MIEHE && getenv("FA_USE_PATCH")) {               // experimental, opt-in
+  if (rows_ok && nel > 0 && c->fam != fa::FAM_PF_MIEHE && dbg.use_patch) {               // experimental, opt-in
     int cap = (rank == 2) ? 6144 : 16384;                       // doubles of LDS for the CSR image
-    if (const char* env = getenv("FA_PATCH_LDS")) cap = std::max(64, atoi(env));
+    if (dbg.patch_lds > 0) cap = std::max(64, dbg.patch_lds);
     const size_t lim = 160 * 1024;
     while (fa::patch_shmem_bytes(cap, nd) > lim) cap -= 256;
     c->patch_path = fa::build_patches(nnode, nel, npe, rank, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
                                       pos.data(), h_rp, nd, cap, fa::kMaxOwn, ps);
     if (c->patch_path) { c->npatch = ps.npatch; c->plds = ps.max_lds; c->lane_redundancy = ps.lane_redundancy; }
-    if (c->patch_path && getenv("FA_VERBOSE"))
+    if (c->patch_path && dbg.verbose)
       fprintf(stderr, "[falcon_assemble] %d patches, %.1f nodes / %.1f elements / %.2f runs per patch, LDS image <= %d doubles, "
               "Gauss-point redundancy %.3f\n", ps.npatch, (double)nnode / ps.npatch, (double)ps.nrec / ps.npatch,
               (double)ps.prun.size() / ps.npatch, ps.max_lds, ps.lane_redundancy);
@@ -659,8 +746,8 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     // default: the higher-order shapes (they have no row kernel) and Hex8 with an isotropic-form tangent (the
     // general-tangent records are too large for a good Hex8 tile: the row kernel stays faster there).
     // FA_TILES=0 / 1 turns the tile kernel off / on for every shape (experiments).
-    const char* env = getenv("FA_TILES");
-    const bool wanted = env ? (atoi(env) != 0) : (c->coop || (p->shape == FA_HEX8_G2 && c->fam != fa::FAM_PF_MIEHE));
+    const bool env = dbg.tiles >= 0;
+    const bool wanted = env ? (dbg.tiles != 0) : (c->coop || (p->shape == FA_HEX8_G2 && c->fam != fa::FAM_PF_MIEHE));
 
     if (P.canon && wanted && nel > 0) {
       const bool keepK = P.keep2 || P.keep3;
@@ -668,13 +755,13 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       // lane order of the pair phase: sorted by element count with (a,b)/(b,a) sharing a lane, except on triangle
       // meshes, where (node, neighbour) order with the staged row write-out measured faster (Triangle6: 1.9 / 2.45 ms)
       const bool tri = p->shape == FA_TRI3_G1 || p->shape == FA_TRI3_G3 || p->shape == FA_TRI6_G3;
-      const bool row_order = getenv("FA_TILE_ORDER") ? atoi(getenv("FA_TILE_ORDER")) != 0 : tri;
+      const bool row_order = dbg.tile_order >= 0 ? dbg.tile_order != 0 : tri;
       P.tile_stage = row_order ? 1 : 0;
       // geometry: two 512-thread workgroups per CU with 80 KB each; element slots of >= kTileBigSlot doubles (27-point
       // Hex20, general tangents in 3-D) get one 1024-thread workgroup with the whole LDS (Hex20 Gauss3^3 at 64^3: 8.8
       // against 10.9 ms)
       const int recw = fa::tile_rec_doubles(rank, c->fam, keepK);
-      const bool big = rank == 3 && (getenv("FA_TILE_BIG") ? atoi(getenv("FA_TILE_BIG")) != 0 : fa::tile_slot_doubles(sh.nip, recw) >= fa::kTileBigSlot);
+      const bool big = rank == 3 && (dbg.tile_big >= 0 ? dbg.tile_big != 0 : fa::tile_slot_doubles(sh.nip, recw) >= fa::kTileBigSlot);
       P.tile_block = big ? fa::kTileBlockBig : fa::kTileBlock;
       c->tile_path = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
                                      nb_ptr.data(), nb.data(), recw, fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0),
@@ -683,7 +770,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       // GET_INT_VECTOR passes keep no records, so a tile set sized for GET_MATRIX0 pays its Gauss-point redundancy for
       // nothing: measured faster than the row / cooperative kernels up to ~3 evaluations per point (Hex20 Gauss3: 5)
       c->tile_force_only = c->tile_path && (env ? true : (ts.point_redundancy < 3.0 && !big));   // big geometry: one workgroup per CU, 1.1 against 0.67 ms for Hex20
-      if (getenv("FA_VERBOSE"))
+      if (dbg.verbose)
         fprintf(stderr, "[falcon_assemble] tiles: %s, %d tiles, %.1f owned nodes / %.1f elements per tile, LDS <= %d bytes, "
                 "Gauss-point redundancy %.3f\n", c->tile_path ? "ok" : "not built", ts.ntile,
                 ts.ntile ? (double)nnode / ts.ntile : 0.0, ts.ntile ? (double)ts.telems.size() / ts.ntile : 0.0,
@@ -694,7 +781,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   c->ngrid_generic = (int)((nel * npe + kBlock - 1) / kBlock);
 
   // ---- upload ----
-  HIP_TRY(hipSetDevice(p->device));
+  FA_ON_DEVICE(p->device);
   fa_status st;
   if ((st = upload(&c->d_conn, p->conn, (size_t)nel * npe))) return st;
   if ((st = upload(&c->d_coords, p->coords, (size_t)nnode * rank))) return st;
@@ -795,7 +882,7 @@ extern "C" double  fa_psi0(const fa_ctx* c) { return c->P.psi0; }
 extern "C" int32_t fa_patch_stats(const fa_ctx* c, double* red) { if (red) *red = c->lane_redundancy; return c->patch_path ? c->npatch : 0; }
 
 extern "C" fa_status fa_pattern_host(const fa_ctx* c, int64_t* row_ptr, int32_t* col_idx) {
-  HIP_TRY(hipSetDevice(c->prob.device));
+  FA_ON_DEVICE(c->prob.device);
   if (row_ptr) HIP_TRY(hipMemcpy(row_ptr, c->d_row_ptr, sizeof(int64_t) * (c->ndof + 1), hipMemcpyDeviceToHost));
   if (col_idx) HIP_TRY(hipMemcpy(col_idx, c->d_col_idx, sizeof(int32_t) * c->nnz, hipMemcpyDeviceToHost));
   return FA_OK;
@@ -817,8 +904,9 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
     return fail(FA_ERR_ARG, "MicroPhaseFractureExt/ExtIt need state00 (stateExt_)");
   // LinearElasticityModel answers GET_MATRIX0 only (LinearElasticityModel.cpp:226-246); force-only is still
   // served here because the kernel supports it.
-  HIP_TRY(hipSetDevice(c->prob.device));
+  FA_ON_DEVICE(c->prob.device);
   hipStream_t st = (hipStream_t)a->stream;
+  c->last_stream = st;
   fa::Params P = c->P;
   P.state = a->state; P.state0 = a->state0; P.stateX = a->state00; P.dt = a->dt; P.dt0 = a->dt0;
   P.K = a->K_values; P.f = a->f_int;
@@ -833,6 +921,11 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   P.err_part = want_err ? c->d_err_part : nullptr;
   const bool want_K = a->K_values != nullptr;
   const bool keep = want_K && (P.keep2 || P.keep3);
+  // bitwise reproducibility exists on the ordered row kernel only: the tile / cooperative / generic kernels add f_int
+  // (and, the last two, K) with atomics whose order varies from run to run
+  if ((a->flags & FA_DETERMINISTIC) && (!c->rows_path || (a->flags & FA_FORCE_GENERIC)))
+    return fail(FA_ERR_UNSUPPORTED, "FA_DETERMINISTIC needs the row kernel (Triangle3/Gauss1, Quad4, Hex8 on a canonical node-major "
+                                    "pattern): this context runs an atomic-scatter kernel");
   int path = c->coop ? fa::PATH_COOP : fa::PATH_GENERIC;
   if (c->rows_path && !(a->flags & FA_FORCE_GENERIC))
     path = (a->flags & FA_DETERMINISTIC) ? fa::PATH_ROWS_ORDERED : (c->patch_path ? fa::PATH_PATCH : (c->pair_path ? fa::PATH_ROWS_PAIR : fa::PATH_ROWS));
@@ -887,7 +980,7 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
 extern "C" fa_status fa_assemble_host(fa_ctx* c, const double* state, const double* state0, const double* state00,
                                       double dt, double dt0, double* K, double* f, double* err_ext, int32_t flags) {
   if (!c || !state || !f) return fail(FA_ERR_ARG, "null argument");
-  HIP_TRY(hipSetDevice(c->prob.device));
+  FA_ON_DEVICE(c->prob.device);
   const size_t nb = sizeof(double) * (size_t)c->ndof;
   auto stage = [&](double** d, const double* h) -> fa_status {
     if (!h) return FA_OK;
@@ -933,7 +1026,8 @@ extern "C" fa_status fa_commit(fa_ctx* c) {
 extern "C" fa_status fa_get_history(const fa_ctx* c, int32_t which, double* out) {
   if (!c || !out || which < 0 || which > 1) return fail(FA_ERR_ARG, "bad argument");
   if (!c->d_hist[which]) return fail(FA_ERR_ARG, "this model keeps no history array");
-  HIP_TRY(hipSetDevice(c->prob.device));
+  FA_ON_DEVICE(c->prob.device);
+  HIP_TRY(hipStreamSynchronize(c->last_stream));      // an assemble on a non-blocking stream may still be writing
   HIP_TRY(hipMemcpy(out, c->d_hist[which], sizeof(double) * c->nel * c->nip, hipMemcpyDeviceToHost));
   return FA_OK;
 }
@@ -941,7 +1035,8 @@ extern "C" fa_status fa_get_history(const fa_ctx* c, int32_t which, double* out)
 extern "C" fa_status fa_set_history(fa_ctx* c, int32_t which, const double* in) {
   if (!c || !in || which < 0 || which > 1) return fail(FA_ERR_ARG, "bad argument");
   if (!c->d_hist[which]) return fail(FA_ERR_ARG, "this model keeps no history array");
-  HIP_TRY(hipSetDevice(c->prob.device));
+  FA_ON_DEVICE(c->prob.device);
+  HIP_TRY(hipStreamSynchronize(c->last_stream));
   HIP_TRY(hipMemcpy(c->d_hist[which], in, sizeof(double) * c->nel * c->nip, hipMemcpyHostToDevice));
   return FA_OK;
 }
@@ -974,7 +1069,7 @@ __global__ void strain_table_kernel(const int32_t* __restrict__ n2e_ptr, const i
 extern "C" fa_status fa_strain_table(fa_ctx* c, double* table, double* weights, void* stream) {
   if (!c || !table || !weights) return fail(FA_ERR_ARG, "null argument");
   if (!c->d_strain) return fail(FA_ERR_ARG, "no strain cache: assemble with FA_STORE_STRAIN first");
-  HIP_TRY(hipSetDevice(c->prob.device));
+  FA_ON_DEVICE(c->prob.device);
   if (c->nnode == 0) return FA_OK;
   hipLaunchKernelGGL(strain_table_kernel, dim3((unsigned)((c->nnode + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      c->d_n2e_ptr, c->d_n2e_ent, c->d_tab, c->d_strain, c->srows, c->str, c->npe, c->nip, c->nnode, table, weights);
@@ -985,7 +1080,7 @@ extern "C" fa_status fa_strain_table(fa_ctx* c, double* table, double* weights, 
 extern "C" fa_status fa_stress_table(fa_ctx* c, double* table, double* weights, void* stream) {
   if (!c || !table || !weights) return fail(FA_ERR_ARG, "null argument");
   if (!c->d_strain) return fail(FA_ERR_ARG, "no strain cache: assemble with FA_STORE_STRAIN first");
-  HIP_TRY(hipSetDevice(c->prob.device));
+  FA_ON_DEVICE(c->prob.device);
   if (c->nnode == 0) return FA_OK;
   fa::Params P = c->P;
   P.strain = c->d_strain;
@@ -1013,7 +1108,7 @@ __global__ __launch_bounds__(1024) void gather_sum_kernel(const double* __restri
 
 extern "C" fa_status fa_gather_sum(fa_ctx* c, const double* vec, const int64_t* idx, int64_t n, double* out, void* stream) {
   if (!c || !vec || !out || n < 0 || (n > 0 && !idx)) return fail(FA_ERR_ARG, "bad argument");
-  HIP_TRY(hipSetDevice(c->prob.device));
+  FA_ON_DEVICE(c->prob.device);
   hipLaunchKernelGGL(gather_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, vec, idx, n, out);
   HIP_TRY(hipGetLastError());
   return FA_OK;
@@ -1026,7 +1121,8 @@ extern "C" double* fa_history_device(fa_ctx* c, int32_t which) {
 extern "C" fa_status fa_get_strain_cache(const fa_ctx* c, double* out) {
   if (!c || !out) return fail(FA_ERR_ARG, "bad argument");
   if (!c->d_strain) return fail(FA_ERR_ARG, "no call with FA_STORE_STRAIN has been made");
-  HIP_TRY(hipSetDevice(c->prob.device));
+  FA_ON_DEVICE(c->prob.device);
+  HIP_TRY(hipStreamSynchronize(c->last_stream));
   HIP_TRY(hipMemcpy(out, c->d_strain, sizeof(double) * c->nel * c->nip * c->srows, hipMemcpyDeviceToHost));
   return FA_OK;
 }

@@ -286,22 +286,24 @@ __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
       const int64_t na = L.cn[a], nb = L.cn[b];
       const int64_t e = e0 + s;
       const int pab = P.canon ? (int)P.pos[(e * NPE + a) * NPE + b] : 0;
+      // every entry written here exists: the canonical layouts hold the blocks of this model by construction
+      // (off[i][j] >= 0 for them) and fa_create has verified a caller's pattern entry by entry -- nothing is dropped
       auto entry = [&](int i, int j) -> int64_t {
-        if (P.canon) { const int o = P.off[i][j]; return (o < 0) ? -1 : P.row_ptr[na * NDOF + i] + (int64_t)pab * P.cnt[i] + o; }
+        if (P.canon) return P.row_ptr[na * NDOF + i] + (int64_t)pab * P.cnt[i] + P.off[i][j];
         return find_col(P, dof(na, i), dof(nb, j));
       };
 #pragma unroll
       for (int i = 0; i < RANK; i++) {
 #pragma unroll
-        for (int j = 0; j < RANK; j++) { const int64_t q = entry(i, j); if (q >= 0) atomicAdd(&P.K[q], Kuu[i][j]); }
-        if constexpr (KEEP) { if (P.keep2) { const int64_t q = entry(i, RANK); if (q >= 0) atomicAdd(&P.K[q], Kup[i]); } }
+        for (int j = 0; j < RANK; j++) atomicAdd(&P.K[entry(i, j)], Kuu[i][j]);
+        if constexpr (KEEP) { if (P.keep2) atomicAdd(&P.K[entry(i, RANK)], Kup[i]); }
       }
       if constexpr (PF) {
-        { const int64_t q = entry(RANK, RANK); if (q >= 0) atomicAdd(&P.K[q], Kpp); }
+        atomicAdd(&P.K[entry(RANK, RANK)], Kpp);
         if constexpr (KEEP) {
           if (P.keep3) {
 #pragma unroll
-            for (int j = 0; j < RANK; j++) { const int64_t q = entry(RANK, j); if (q >= 0) atomicAdd(&P.K[q], Kpu[j]); }
+            for (int j = 0; j < RANK; j++) atomicAdd(&P.K[entry(RANK, j)], Kpu[j]);
           }
         }
       }

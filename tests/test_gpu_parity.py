@@ -478,3 +478,88 @@ def test_micro_ext_needs_state_ext():
     st = torch.zeros(asm.ndof, dtype=torch.float64, device=dev); f = torch.zeros_like(st)
     with pytest.raises(capi.FaError, match="stateExt_"):
         asm.assemble(st, None, f, flags=capi.OVERWRITE)
+
+
+# ---- boundary behaviour ----
+def test_pattern_with_a_missing_entry_is_refused():
+    """A caller-supplied pattern that lacks an entry the model writes is FA_ERR_ARG at fa_create (the reference's
+    MatrixBuilder::addBlock would add it or throw); the same pattern with every entry assembles on the generic kernel."""
+    shape, model, material = capi.QUAD4_G2, capi.PHASE_FRACTURE, capi.AMOR_PHASE
+    coords, conn, st, kw, cfg = make_case(shape, model, material, 1)
+    rp, ci = po.pattern(coords.shape[0], conn, 3, 2)
+    rows = [list(ci[rp[r]:rp[r + 1]][::-1]) for r in range(len(rp) - 1)]          # reversed rows: not a canonical layout
+
+    def build(rows):
+        rp2 = np.zeros(len(rows) + 1, dtype=np.int64); rp2[1:] = np.cumsum([len(x) for x in rows])
+        return rp2, np.array([c for row in rows for c in row], dtype=np.int32)
+    rp2, ci2 = build(rows)
+    asm = capi.Assembler(shape, model, material, coords, conn, row_ptr=rp2, col_idx=ci2, ndof=len(rp2) - 1, **kw)
+    assert not asm.uses_row_kernel
+    K, f, _ = asm.assemble_host(st, np.zeros(asm.nnz), flags=capi.OVERWRITE)
+    ref = po.assemble(cfg, coords, conn, rp, ci, st)
+    src = np.concatenate([np.arange(rp[r], rp[r + 1])[::-1] for r in range(len(rp) - 1)])
+    assert rel_rowmax_err(rp2, K, ref["K"][src]) < TOL and vec_err(f, ref["f"]) < TOL
+    del rows[40][3]
+    rp3, ci3 = build(rows)
+    with pytest.raises(capi.FaError, match="has no entry"):
+        capi.Assembler(shape, model, material, coords, conn, row_ptr=rp3, col_idx=ci3, ndof=len(rp3) - 1, **kw)
+
+
+@pytest.mark.parametrize("shape", [capi.QUAD8_G2, capi.HEX20_G2])
+def test_deterministic_is_refused_without_a_row_kernel(shape):
+    """FA_DETERMINISTIC is only honoured by the ordered row kernel; the other paths say so instead of ignoring it."""
+    import torch
+    coords, conn, st, kw, cfg = make_case(shape, capi.LINEAR_ELASTICITY, capi.HOOKE)
+    asm = capi.Assembler(shape, capi.LINEAR_ELASTICITY, capi.HOOKE, coords, conn, **kw)
+    dev = torch.device("cuda", 0)
+    K = torch.zeros(asm.nnz, dtype=torch.float64, device=dev); f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+    with pytest.raises(capi.FaError, match="FA_DETERMINISTIC"):
+        asm.assemble(torch.from_numpy(st).to(dev), K, f, flags=capi.OVERWRITE | capi.DETERMINISTIC)
+
+
+@pytest.mark.parametrize("shape,model,material,keep", [
+    (capi.HEX8_G2, capi.PHASE_FRACTURE, capi.AMOR_PHASE, 1),          # Hex8 row kernel (default: tile kernel)
+    (capi.HEX8_G2, capi.PHASE_FRACTURE_EXTIT, capi.BOURDIN_PHASE, 0),
+    (capi.QUAD8_G3, capi.PHASE_FRACTURE, capi.AMOR_PHASE, 1),         # cooperative kernel (default: tile kernel)
+    (capi.TRI6_G3, capi.PHASE_FRACTURE_EXTIT, capi.MIEHE_PHASE, 0),
+    (capi.HEX20_G2, capi.LINEAR_ELASTICITY, capi.HOOKE, 0),
+    (capi.TRI3_G3, capi.PHASE_FRACTURE, capi.BOURDIN_PHASE, 0)])
+def test_non_default_kernel_paths(shape, model, material, keep, monkeypatch):
+    """FA_TILES=0 (read per fa_create): the kernels that serve a shape when the tile kernel is off -- what a caller's
+    non-canonical pattern gets on the higher-order shapes -- run inside the default test invocation."""
+    monkeypatch.setenv("FA_TILES", "0")
+    run_both(shape, model, material, keep=keep)
+    run_both(shape, model, material, keep=keep, flags=capi.ACCUMULATE, kind=capi.PATTERN_WRITTEN, shuffle=True)
+    run_both(shape, model, material, keep=keep, want_K=False)
+
+
+def test_cooperative_kernel_on_a_callers_pattern():
+    """Quad8 with a caller-supplied (reversed-row) pattern: the cooperative kernel with per-entry column search."""
+    shape, model, material = capi.QUAD8_G3, capi.PHASE_FRACTURE, capi.AMOR_PHASE
+    coords, conn, st, kw, cfg = make_case(shape, model, material, 1)
+    rp, ci = po.pattern(coords.shape[0], conn, 3, 2)
+    ci2 = np.concatenate([ci[rp[r]:rp[r + 1]][::-1] for r in range(len(rp) - 1)]).astype(np.int32)
+    src = np.concatenate([np.arange(rp[r], rp[r + 1])[::-1] for r in range(len(rp) - 1)])
+    asm = capi.Assembler(shape, model, material, coords, conn, row_ptr=rp, col_idx=ci2, ndof=len(rp) - 1, **kw)
+    K, f, _ = asm.assemble_host(st, np.zeros(asm.nnz), flags=capi.OVERWRITE)
+    ref = po.assemble(cfg, coords, conn, rp, ci, st)
+    assert rel_rowmax_err(rp, K, ref["K"][src]) < TOL and vec_err(f, ref["f"]) < TOL
+
+
+def test_host_getters_wait_for_a_side_stream():
+    """fa_assemble on a non-blocking side stream followed at once by the blocking host getters."""
+    import torch
+    shape, model, material = capi.QUAD4_G2, capi.PHASE_FRACTURE, capi.AMOR_PHASE
+    coords, conn = meshgen.grid_quad4(300, 300)
+    kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.05)
+    asm = capi.Assembler(shape, model, material, coords, conn, **kw)
+    dev = torch.device("cuda", 0)
+    st = torch.from_numpy(meshgen.smooth_state(coords, 3, l0=0.05)).to(dev)
+    K = torch.zeros(asm.nnz, dtype=torch.float64, device=dev); f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    asm.assemble(st, K, f, flags=capi.OVERWRITE | capi.STORE_STRAIN, stream=side.cuda_stream)
+    h1 = asm.get_history(1); s1 = asm.get_strain_cache()
+    torch.cuda.synchronize()
+    assert np.array_equal(h1, asm.get_history(1)) and np.array_equal(s1, asm.get_strain_cache())
+    assert h1.max() > 0
