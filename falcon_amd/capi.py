@@ -51,7 +51,7 @@ class AssembleArgs(C.Structure):
 
 EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_nip_total", "fa_ndof_per_node",
            "fa_strain_rows", "fa_uses_row_kernel", "fa_psi0", "fa_patch_stats", "fa_pattern_host", "fa_pattern_device",
-           "fa_assemble", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
+           "fa_assemble", "fa_assemble_noalloc", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
            "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum", "fa_strain_table", "fa_stress_table"]
 
 _lib = None
@@ -76,6 +76,7 @@ def lib():
         L.fa_pattern_host.argtypes = [vp, vp, vp]
         L.fa_pattern_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
         L.fa_assemble.argtypes = [vp, C.POINTER(AssembleArgs)]
+        L.fa_assemble_noalloc.argtypes = [vp, C.POINTER(AssembleArgs)]
         L.fa_assemble_host.argtypes = [vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, C.c_int32]
         L.fa_commit.argtypes = [vp]
         L.fa_get_history.argtypes = [vp, C.c_int32, vp]
@@ -166,7 +167,8 @@ class Assembler:
 
     # ---- device path (torch tensors on cuda:device, float64) ----
     def assemble(self, state, K=None, f=None, *, state0=None, state00=None, dt=0.0, dt0=0.0, err_ext=None,
-                 flags=ACCUMULATE, stream=None):
+                 flags=ACCUMULATE, stream=None, noalloc=False):
+        """noalloc=True goes through fa_assemble_noalloc (static device scratch, no allocation inside the call)."""
         import torch
         def ptr(t, n):
             if t is None:
@@ -177,7 +179,7 @@ class Assembler:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         a = AssembleArgs(ptr(state, self.ndof), ptr(state0, self.ndof), ptr(state00, self.ndof), dt, dt0,
                          ptr(K, self.nnz), ptr(f, self.ndof), ptr(err_ext, 1), flags, stream)
-        _check(lib().fa_assemble(self.h, C.byref(a)))
+        _check((lib().fa_assemble_noalloc if noalloc else lib().fa_assemble)(self.h, C.byref(a)))
 
     # ---- host path (numpy vectors; H2D + assemble + D2H inside the library) ----
     def assemble_host(self, state, K=None, f=None, *, state0=None, state00=None, dt=0.0, dt0=0.0,

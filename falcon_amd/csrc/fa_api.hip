@@ -288,6 +288,27 @@ __global__ void reduce_err_kernel(const double* part, int n, double* out) {
   if (threadIdx.x == 0) *out = s[0];
 }
 
+// ---- scratch of the allocation-free entry point (fa_assemble_noalloc) ----
+// Per-workgroup partial sums of errExt_ live in this file-scope device array instead of a hipMalloc'ed buffer.  Every
+// GPU the library runs on holds its own copy (kNoAllocMaxParts doubles = 1 MiB) until the process ends.  In host code
+// the name `scratch` is only a stand-in: the array's device address is resolved once per device with
+// hipGetSymbolAddress (with that device current) and kept in g_scratch_ptr; host code uses that pointer everywhere.
+constexpr int kNoAllocMaxParts = 1 << 17;
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) double scratch[kNoAllocMaxParts];
+double* g_scratch_ptr[kMaxDevices] = {};
+
+// the caller has made `dev` current
+fa_status resolve_scratch(int dev) {
+  if (dev < 0 || dev >= kMaxDevices) return fail(FA_ERR_ARG, "device ordinal %d out of range", dev);
+  if (g_scratch_ptr[dev]) return FA_OK;
+  void* ptr = nullptr;
+  hipError_t rc = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+  if (rc != hipSuccess || !ptr) return fail(FA_ERR_HIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(rc));
+  g_scratch_ptr[dev] = static_cast<double*>(ptr);
+  return FA_OK;
+}
+
 }  // namespace
 
 struct fa_ctx {
@@ -298,7 +319,7 @@ struct fa_ctx {
   int ngrid_coop = 0;
   int nwg = 0, max_valence = 0, ngrid_generic = 0, block = 0, npatch = 0, plds = 0;
   bool patch_path = false, pair_path = false, tile_path = false, tile_force_only = false;
-  int ntile2 = 0, ntile3 = 0;
+  int ntile2 = 0, ntile3 = 0, max_parts = 0;   // max_parts: workgroups of the largest launch (errExt_ partial sums)
   double lane_redundancy = 1.0;
   fa::launch_fn launch = nullptr;
   fa::Params P{};
@@ -783,6 +804,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   // ---- upload ----
   FA_ON_DEVICE(p->device);
   fa_status st;
+  if ((st = resolve_scratch(p->device))) return st;   // set-up of fa_assemble_noalloc: once per device, device current
   if ((st = upload(&c->d_conn, p->conn, (size_t)nel * npe))) return st;
   if ((st = upload(&c->d_coords, p->coords, (size_t)nnode * rank))) return st;
   if ((st = upload(&c->d_row_ptr, h_rp, (size_t)c->ndof + 1))) return st;
@@ -831,8 +853,9 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[0], nipt, p->model == FA_PHASE_FRACTURE ? P.psi0 : 0.0);   // preHist_.phasef_ = 0 (MicroPhaseFractureModel.cpp:359)
     hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[1], nipt, 0.0);
   }
+  c->max_parts = std::max(std::max(std::max(std::max(std::max(c->nwg, c->ntile2), c->ngrid_generic), c->npatch), c->ngrid_coop), c->ntile3);
   if (p->model == FA_PHASE_FRACTURE_EXTIT || p->model == FA_MICRO_PHASE_FRACTURE_EXTIT)
-    HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(std::max(std::max(std::max(std::max(c->nwg, c->ntile2), c->ngrid_generic), c->npatch), c->ngrid_coop), c->ntile3)));
+    HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(c->max_parts, 1)));
   HIP_TRY(hipDeviceSynchronize());
 
   P.conn = c->d_conn; P.coords = c->d_coords; P.row_ptr = c->d_row_ptr; P.col_idx = c->d_col_idx;
@@ -894,7 +917,9 @@ extern "C" fa_status fa_pattern_device(const fa_ctx* c, const int64_t** row_ptr,
   return FA_OK;
 }
 
-extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
+// noalloc: the call must not allocate -- the strain cache has to exist already and the errExt_ partials go to the
+// file-scope scratch array (through its resolved device address) instead of the context's buffer
+static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noalloc) {
   if (!c || !a) return fail(FA_ERR_ARG, "null argument");
   if (!a->state || !a->f_int) return fail(FA_ERR_ARG, "state and f_int are required");
   const int model = c->prob.model;
@@ -914,11 +939,24 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   P.overwrite = (a->flags & FA_OVERWRITE) ? 1 : 0;
   P.strain = nullptr;
   if (a->flags & FA_STORE_STRAIN) {
-    if (!c->d_strain) HIP_TRY(hipMalloc((void**)&c->d_strain, sizeof(double) * std::max<int64_t>(1, c->nel * c->nip * c->srows)));
+    if (!c->d_strain) {
+      if (noalloc) return fail(FA_ERR_ARG, "fa_assemble_noalloc: FA_STORE_STRAIN needs the strain cache of an earlier fa_assemble call with FA_STORE_STRAIN (allocating it here is not allowed)");
+      HIP_TRY(hipMalloc((void**)&c->d_strain, sizeof(double) * std::max<int64_t>(1, c->nel * c->nip * c->srows)));
+    }
     P.strain = c->d_strain;
   }
   const bool want_err = (model == FA_PHASE_FRACTURE_EXTIT || model == FA_MICRO_PHASE_FRACTURE_EXTIT) && a->err_ext;
-  P.err_part = want_err ? c->d_err_part : nullptr;
+  double* err_part = c->d_err_part;
+  if (want_err && noalloc) {
+    if (c->max_parts > kNoAllocMaxParts)
+      return fail(FA_ERR_ARG, "fa_assemble_noalloc: this mesh needs %d partial sums of errExt_, the static scratch holds %d", c->max_parts, kNoAllocMaxParts);
+    fa_status rs = resolve_scratch(c->prob.device);
+    if (rs != FA_OK) return rs;
+    err_part = g_scratch_ptr[c->prob.device];
+    // every call on this GPU shares the array and finds the last call's contents: clear what this call will use
+    HIP_TRY(hipMemsetAsync(err_part, 0, sizeof(double) * (size_t)c->max_parts, st));
+  }
+  P.err_part = want_err ? err_part : nullptr;
   const bool want_K = a->K_values != nullptr;
   const bool keep = want_K && (P.keep2 || P.keep3);
   // bitwise reproducibility exists on the ordered row kernel only: the tile / cooperative / generic kernels add f_int
@@ -971,11 +1009,15 @@ extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) {
   if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   if (want_err) {
     const int nparts = (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) ? c->nwg : (path == fa::PATH_ROWS_PAIR ? c->ntile2 : (path == fa::PATH_TILES ? c->ntile3 : grid));
-    hipLaunchKernelGGL(reduce_err_kernel, dim3(1), dim3(256), 0, st, c->d_err_part, nparts, a->err_ext);
+    hipLaunchKernelGGL(reduce_err_kernel, dim3(1), dim3(256), 0, st, err_part, nparts, a->err_ext);
     HIP_TRY(hipGetLastError());
   }
   return FA_OK;
 }
+
+extern "C" fa_status fa_assemble(fa_ctx* c, const fa_assemble_args* a) { return assemble_impl(c, a, false); }
+
+extern "C" fa_status fa_assemble_noalloc(fa_ctx* c, const fa_assemble_args* a) { return assemble_impl(c, a, true); }
 
 extern "C" fa_status fa_assemble_host(fa_ctx* c, const double* state, const double* state0, const double* state00,
                                       double dt, double dt0, double* K, double* f, double* err_ext, int32_t flags) {

@@ -141,6 +141,17 @@ fa_status fa_pattern_device(const fa_ctx* ctx, const int64_t** row_ptr, const in
  * call (PhaseFractureModel.cpp:703). */
 fa_status fa_assemble(fa_ctx* ctx, const fa_assemble_args* args);
 
+/* fa_assemble for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same kernels and same results
+ * as fa_assemble, but the call allocates nothing: the per-workgroup partial sums of errExt_ (ExtIt models) go to a
+ * file-scope device array of the library -- 131072 doubles = 1 MiB, held by every GPU the library runs on until the
+ * process ends -- instead of the context's hipMalloc'ed buffer.  Limits: a mesh whose launch has more than 131072
+ * workgroups is refused with FA_ERR_ARG when err_ext is requested (about 8 M Quad4 or 2.5 M Hex8 elements; models
+ * without errExt_ have no limit); FA_STORE_STRAIN is accepted only once an earlier fa_assemble call has created the
+ * strain cache.  All calls on one GPU share the array: calls that overlap on one GPU (different streams, different
+ * contexts) race on it -- serialise them. */
+fa_status fa_assemble_noalloc(fa_ctx* ctx, const fa_assemble_args* args);
+
 /* Same with HOST vectors (what a Jive shim holds): H2D state, assemble, D2H K/f, synchronous.
  * K_values/f_int are accumulated into or overwritten on the host according to flags. */
 fa_status fa_assemble_host(fa_ctx* ctx, const double* state, const double* state0, const double* state00,

@@ -1,0 +1,79 @@
+"""fa_assemble_noalloc: the allocation-free variant of fa_assemble (static device scratch for the errExt_ partial
+sums) against fa_assemble itself, through the C ABI, on two calls in a row, the second with a smaller input."""
+import numpy as np
+import pytest
+
+from falcon_amd import capi, meshgen
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def _case(shape, model, material, mesh, seed):
+    import torch
+    coords, conn = mesh
+    coords = meshgen.distort(coords, conn, 0.1, seed)
+    kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2, beta=250.0 if model >= capi.MICRO_PHASE_FRACTURE else 6500.0)
+    asm = capi.Assembler(shape, model, material, coords, conn, **kw)
+    nd = asm.ndofpn; rank = asm.rank
+    st = meshgen.smooth_state(coords, nd, seed=seed, amp=5e-3, noise=1e-4, l0=0.3)
+    rng = np.random.default_rng(seed)
+    st0 = st.copy(); st00 = st.copy()
+    st0[rank::nd] += rng.uniform(-0.02, 0.02, coords.shape[0]); st00[rank::nd] += rng.uniform(-0.02, 0.02, coords.shape[0])
+    dev = torch.device("cuda", 0)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return asm, d(st), d(st0), d(st00), dev
+
+
+def _run(asm, st, st0, st00, dev, noalloc, flags=capi.OVERWRITE):
+    import torch
+    K = torch.full((asm.nnz,), 0.25, dtype=torch.float64, device=dev)
+    f = torch.full((asm.ndof,), -0.5, dtype=torch.float64, device=dev)
+    err = torch.full((1,), 7.0, dtype=torch.float64, device=dev)
+    asm.assemble(st, K, f, state0=st0, state00=st00, dt=0.7, dt0=0.4, err_ext=err, flags=flags, noalloc=noalloc)
+    torch.cuda.synchronize()
+    return K.cpu().numpy(), f.cpu().numpy(), err.item()
+
+
+def _close(a, b):
+    return np.abs(a - b).max() <= TOL * max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("shape,model,material,big,small", [
+    (capi.QUAD4_G2, capi.PHASE_FRACTURE_EXTIT, capi.AMOR_PHASE, lambda: meshgen.grid_quad4(90, 70), lambda: meshgen.grid_quad4(23, 17)),
+    (capi.HEX8_G2, capi.PHASE_FRACTURE_EXTIT, capi.BOURDIN_PHASE, lambda: meshgen.grid_hex8(12, 11, 10), lambda: meshgen.grid_hex8(5, 4, 3)),
+    (capi.QUAD8_G3, capi.MICRO_PHASE_FRACTURE_EXTIT, capi.MIEHE_PHASE, lambda: meshgen.grid_quad8(30, 20), lambda: meshgen.grid_quad8(6, 5)),
+])
+def test_noalloc_matches_fa_assemble_twice_in_a_row(shape, model, material, big, small):
+    a1 = _case(shape, model, material, big(), 3)
+    a2 = _case(shape, model, material, small(), 4)
+    ref1 = _run(*a1, noalloc=False)
+    ref2 = _run(*a2, noalloc=False)
+    # two calls in a row through the static scratch, the second with the smaller input; then the big one again
+    for args, ref in ((a1, ref1), (a2, ref2), (a1, ref1)):
+        K, f, err = _run(*args, noalloc=True)
+        assert _close(K, ref[0]) and _close(f, ref[1])
+        assert ref[2] > 0 and abs(err - ref[2]) <= TOL * ref[2]
+    # accumulate mode and a force-only call
+    K, f, err = _run(*a2, noalloc=True, flags=capi.ACCUMULATE)
+    assert _close(K - 0.25, ref2[0]) and _close(f + 0.5, ref2[1]) and abs(err - ref2[2]) <= TOL * ref2[2]
+
+
+def test_noalloc_refuses_what_it_cannot_serve():
+    import torch
+    asm, st, st0, st00, dev = _case(capi.QUAD4_G2, capi.PHASE_FRACTURE_EXTIT, capi.AMOR_PHASE, meshgen.grid_quad4(12, 9), 5)
+    f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+    with pytest.raises(capi.FaError, match="FA_STORE_STRAIN"):           # would have to allocate the strain cache
+        asm.assemble(st, None, f, state0=st0, state00=st00, flags=capi.OVERWRITE | capi.STORE_STRAIN, noalloc=True)
+    asm.assemble(st, None, f, state0=st0, state00=st00, flags=capi.OVERWRITE | capi.STORE_STRAIN)
+    asm.assemble(st, None, f, state0=st0, state00=st00, flags=capi.OVERWRITE | capi.STORE_STRAIN, noalloc=True)   # cache exists now
+    torch.cuda.synchronize()
+    # a launch with more workgroups than the scratch has slots (131072): refused with a clear error, nothing launched
+    coords, conn = meshgen.grid_quad4(3000, 3000)
+    big = capi.Assembler(capi.QUAD4_G2, capi.PHASE_FRACTURE_EXTIT, capi.AMOR_PHASE, coords, conn, young=210.0, gc=2.7e-3, l0=0.05)
+    s = torch.zeros(big.ndof, dtype=torch.float64, device=dev); fb = torch.zeros(big.ndof, dtype=torch.float64, device=dev)
+    err = torch.zeros(1, dtype=torch.float64, device=dev)
+    with pytest.raises(capi.FaError, match="partial sums"):
+        big.assemble(s, None, fb, state0=s, state00=s, err_ext=err, flags=capi.OVERWRITE, noalloc=True)
+    big.assemble(s, None, fb, state0=s, state00=s, err_ext=None, flags=capi.OVERWRITE, noalloc=True)   # no errExt_: no limit
+    torch.cuda.synchronize()
