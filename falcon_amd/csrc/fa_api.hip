@@ -45,7 +45,12 @@ struct DebugOptions {
   int  tile_order = -1;   // FA_TILE_ORDER=0|1: pair lanes count-sorted with shared (a,b)/(b,a) lanes | row order
   int  tile_big = -1;     // FA_TILE_BIG=0|1: two 512-thread workgroups per CU | one of 1024 threads
   int  emat = -1;         // FA_EMAT=0|1: element-matrix tile kernel (Quad4 / Triangle3) off / on
-  int  emat_nodes = 0;    // FA_EMAT_NODES=n: owned nodes per element-matrix tile (0: default)
+  int  fvec = -1;         // FA_FVEC=0|1: force-vector kernel (GET_INT_VECTOR passes of Quad4 / Triangle3) off / on
+  int  persist = -1;      // FA_PERSIST=0|1: persistent LDS-DMA kernels off / on
+  int  fvec_blk = 0;      // FA_FVEC_BLK=192|256|320: its workgroup size = elements per tile (0: default)
+  int  emat_lds = 0;      // FA_EMAT_LDS=n: LDS bytes of one element-matrix tile (0: default)
+  int  emat_lpe = 0;      // FA_EMAT_LPE=1|2: lanes per element of its GET_MATRIX0 passes (0: default)
+  int  emat_lpe_f = 0;    // FA_EMAT_LPE_F=1|2: the same for GET_INT_VECTOR passes
   bool no_pair = false;   // FA_NO_PAIR=1: no lane pairs for Quad4
   bool pair_3d = false;   // FA_PAIR_3D=1: lane pairs for Hex8 as well
   int  pad_rec = 1;       // FA_PAD_REC=0: lane records not padded per tile
@@ -56,7 +61,9 @@ struct DebugOptions {
     DebugOptions o;
     auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1);
-    o.emat = geti("FA_EMAT", -1); o.emat_nodes = geti("FA_EMAT_NODES", 0);
+    o.emat = geti("FA_EMAT", -1); o.emat_lds = geti("FA_EMAT_LDS", 0); o.emat_lpe = geti("FA_EMAT_LPE", 0);
+    o.emat_lpe_f = geti("FA_EMAT_LPE_F", 0); o.fvec = geti("FA_FVEC", -1); o.fvec_blk = geti("FA_FVEC_BLK", 0);
+    o.persist = geti("FA_PERSIST", -1);
     o.no_pair = getenv("FA_NO_PAIR") != nullptr; o.pair_3d = getenv("FA_PAIR_3D") != nullptr;
     o.pad_rec = geti("FA_PAD_REC", 1); o.use_patch = getenv("FA_USE_PATCH") != nullptr;
     o.patch_lds = geti("FA_PATCH_LDS", 0); o.verbose = getenv("FA_VERBOSE") != nullptr;
@@ -269,7 +276,7 @@ fa::launch_fn launcher_for(int shape) {
 template <class T>
 fa_status upload(T** dst, const T* src, size_t n) {
   HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
-  if (n) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+  if (n && src) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
   return FA_OK;
 }
 
@@ -311,6 +318,18 @@ fa_status resolve_scratch(int dev) {
 
 }  // namespace
 
+// one tile set on the device (element-matrix kernel: one for GET_MATRIX0, one for GET_INT_VECTOR passes)
+struct TileDev {
+  bool ok = false;
+  int ntile = 0, lds = 0, lpe = 1, block = 256;
+  int conn_stride = 0, maxn = 0, maxe = 0, plds = 0, pgrid = 0;   // persistent form: staging capacities, LDS bytes, grid
+  bool persistent = false;
+  double redundancy = 0.0;
+  uint32_t* eslot = nullptr; uint32_t* nval = nullptr;
+  int32_t *tinfo = nullptr, *tnodes = nullptr, *telems = nullptr; uint16_t* tconn = nullptr;
+  uint32_t *tpairs = nullptr, *tents = nullptr;
+};
+
 struct fa_ctx {
   fa_problem prob{};
   int rank = 0, npe = 0, nip = 0, str = 0, ndofpn = 0, fam = 0, srows = 0;
@@ -319,6 +338,7 @@ struct fa_ctx {
   int ngrid_coop = 0;
   int nwg = 0, max_valence = 0, ngrid_generic = 0, block = 0, npatch = 0, plds = 0;
   bool patch_path = false, pair_path = false, tile_path = false, tile_force_only = false;
+  int ncu = 256;
   int ntile2 = 0, ntile3 = 0, max_parts = 0;   // max_parts: workgroups of the largest launch (errExt_ partial sums)
   double lane_redundancy = 1.0;
   fa::launch_fn launch = nullptr;
@@ -336,6 +356,8 @@ struct fa_ctx {
   // staging for fa_assemble_host
   double *s_state = nullptr, *s_state0 = nullptr, *s_state00 = nullptr, *s_K = nullptr, *s_f = nullptr, *s_err = nullptr;
   std::vector<double> h_tmp;
+  TileDev ematK, ematF;                // element-matrix kernel (Quad4 / Triangle3)
+  TileDev fvec;                        // force-vector kernel (Quad4 / Triangle3)
   DebugOptions dbg;
   hipStream_t last_stream = nullptr;   // stream of the last fa_assemble: the host getters / setters wait for it
 };
@@ -349,7 +371,10 @@ extern "C" void fa_destroy(fa_ctx* c) {
                    c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part,
                    c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err,
                    c->d_pn_ptr, c->d_pe_ptr, c->d_pr_ptr, c->d_pnode, c->d_poff, c->d_prec, c->d_prun,
-                   c->d_tinfo, c->d_tnodes, c->d_telems, c->d_tconn, c->d_tpairs, c->d_tents };
+                   c->d_tinfo, c->d_tnodes, c->d_telems, c->d_tconn, c->d_tpairs, c->d_tents,
+                   c->ematK.tinfo, c->ematK.tnodes, c->ematK.telems, c->ematK.tconn, c->ematK.tpairs, c->ematK.tents,
+                   c->ematF.tinfo, c->ematF.tnodes, c->ematF.telems, c->ematF.tconn, c->ematF.tpairs, c->ematF.tents,
+                   c->fvec.tinfo, c->fvec.tnodes, c->fvec.telems, c->fvec.tconn, c->fvec.tpairs, c->fvec.tents, c->fvec.eslot, c->fvec.nval };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete c;
 }
@@ -798,13 +823,77 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
                 ts.lds_bytes, ts.point_redundancy);
     }
   }
+  // ---- element-matrix kernel (Quad4, Triangle3/Gauss1): one tile set sized for the element-matrix slots of
+  //      GET_MATRIX0 passes, one with f-only slots (larger tiles) for GET_INT_VECTOR passes ----
+  fa::TileSet tsK, tsF;
+  {
+    const bool shape_ok = p->shape == FA_QUAD4_G2 || p->shape == FA_TRI3_G1;
+    const bool wanted = dbg.emat >= 0 ? dbg.emat != 0 : false;
+    if (shape_ok && wanted && P.canon && nel > 0) {
+      const bool keepK = P.keep2 || P.keep3;
+      const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE;
+      const int nodw = fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0);
+      const int budget = dbg.emat_lds > 0 ? dbg.emat_lds : 80 * 1024;
+      auto lpe_of = [&](int want) { return (want == 2 && sh.nip % 2 == 0) ? 2 : 1; };
+      fa::TileOpts o;
+      o.no_tab = true; o.no_f_image = true; o.order = 2;
+      c->ematK.lpe = lpe_of(dbg.emat_lpe > 0 ? dbg.emat_lpe : 2);
+      o.slot_doubles = fa::emat_slot_doubles(rank, npe, pf, true, keepK); o.max_el = 256 / c->ematK.lpe;
+      c->ematK.ok = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
+                                    nb_ptr.data(), nb.data(), 0, nodw, budget, 256, true, tsK, o);
+      c->ematF.lpe = lpe_of(dbg.emat_lpe_f > 0 ? dbg.emat_lpe_f : 1);
+      o.slot_doubles = fa::emat_slot_doubles(rank, npe, pf, false, false); o.max_el = 256 / c->ematF.lpe; o.diag_only = true;
+      c->ematF.ok = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
+                                    nb_ptr.data(), nb.data(), 0, nodw, budget, 256, true, tsF, o);
+      if (c->ematK.ok) { c->ematK.ntile = tsK.ntile; c->ematK.lds = tsK.lds_bytes; c->ematK.redundancy = tsK.point_redundancy; }
+      if (c->ematF.ok) { c->ematF.ntile = tsF.ntile; c->ematF.lds = tsF.lds_bytes; c->ematF.redundancy = tsF.point_redundancy; }
+      if (dbg.verbose)
+        fprintf(stderr, "[falcon_assemble] element-matrix tiles: K %s %d tiles (%.1f nodes, LDS <= %d, redundancy %.3f, %d lanes/element), "
+                "f %s %d tiles (%.1f nodes, LDS <= %d, redundancy %.3f, %d lanes/element)\n",
+                c->ematK.ok ? "ok" : "not built", tsK.ntile, tsK.ntile ? (double)nnode / tsK.ntile : 0.0, tsK.lds_bytes, tsK.point_redundancy, c->ematK.lpe,
+                c->ematF.ok ? "ok" : "not built", tsF.ntile, tsF.ntile ? (double)nnode / tsF.ntile : 0.0, tsF.lds_bytes, tsF.point_redundancy, c->ematF.lpe);
+    }
+  }
+  // ---- force-vector kernel (GET_INT_VECTOR passes of Quad4 / Triangle3): needs the canonical dof numbering only ----
+  fa::TileSet tsV;
+  {
+    const bool shape_ok = p->shape == FA_QUAD4_G2 || p->shape == FA_TRI3_G1;
+    const bool wanted = dbg.fvec >= 0 ? dbg.fvec != 0 : true;
+    if (shape_ok && wanted && canonical_dofs && c->ndof == nnode * nd && nel > 0 && maxval <= 8) {
+      const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE;
+      const int nodw = fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0);
+      c->fvec.block = (dbg.fvec_blk == 192 || dbg.fvec_blk == 256 || dbg.fvec_blk == 320) ? dbg.fvec_blk : 192;
+      fa::TileOpts o;
+      o.no_tab = true; o.no_f_image = true; o.fvec = maxval; o.own_doubles = maxval * nd; o.max_el = c->fvec.block;
+      o.conn_pad4 = true; o.max_all = 2 * c->fvec.block;
+      c->fvec.ok = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
+                                   nb_ptr.data(), nb.data(), 0, nodw, 48 * 1024, c->fvec.block, false, tsV, o);
+      if (c->fvec.ok) {
+        c->fvec.ntile = tsV.ntile; c->fvec.lds = tsV.lds_bytes; c->fvec.redundancy = tsV.point_redundancy; c->fvec.lpe = maxval;
+        c->fvec.conn_stride = tsV.conn_stride;
+        // persistent LDS-DMA form: PhaseFracture / MicroPhaseFracture / LinearElasticity, workgroups of 192 or 256
+        const bool model_ok = p->model == FA_LINEAR_ELASTICITY || p->model == FA_PHASE_FRACTURE || p->model == FA_MICRO_PHASE_FRACTURE;
+        if (model_ok && (dbg.persist != 0) && (c->fvec.block == 192 || c->fvec.block == 256)) {
+          c->fvec.maxn = (tsV.max_all + 63) / 64 * 64; c->fvec.maxe = (tsV.max_el + 63) / 64 * 64;
+          const bool hist = p->model != FA_LINEAR_ELASTICITY;
+          c->fvec.plds = 2 * fa::stage_bytes_host(pf, sh.nip, c->fvec.maxn, c->fvec.maxe, hist) + tsV.max_own * maxval * nd * 8;
+          c->fvec.persistent = c->fvec.plds <= 160 * 1024 && c->fvec.maxe <= c->fvec.block;
+        }
+      }
+      if (dbg.verbose)
+        fprintf(stderr, "[falcon_assemble] force-vector tiles: %s, %d tiles of <= %d elements (%.1f nodes, %.1f elements per tile), LDS <= %d bytes, "
+                "Gauss-point redundancy %.3f\n", c->fvec.ok ? "ok" : "not built", tsV.ntile, c->fvec.block,
+                tsV.ntile ? (double)nnode / tsV.ntile : 0.0, tsV.ntile ? (double)tsV.telems.size() / tsV.ntile : 0.0, tsV.lds_bytes, tsV.point_redundancy);
+    }
+  }
   c->nwg = rows_ok ? (int)wg_start.size() - 1 : 0;
   c->ngrid_generic = (int)((nel * npe + kBlock - 1) / kBlock);
 
   // ---- upload ----
   FA_ON_DEVICE(p->device);
   fa_status st;
-  if ((st = resolve_scratch(p->device))) return st;   // set-up of fa_assemble_noalloc: once per device, device current
+  if ((st = resolve_scratch(p->device))) return st;
+  { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && v > 0) c->ncu = v; }   // set-up of fa_assemble_noalloc: once per device, device current
   if ((st = upload(&c->d_conn, p->conn, (size_t)nel * npe))) return st;
   if ((st = upload(&c->d_coords, p->coords, (size_t)nnode * rank))) return st;
   if ((st = upload(&c->d_row_ptr, h_rp, (size_t)c->ndof + 1))) return st;
@@ -846,6 +935,22 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     if ((st = upload(&c->d_tpairs, ts.tpairs.data(), ts.tpairs.size()))) return st;
     if ((st = upload(&c->d_tents, ts.tents.data(), std::max<size_t>(ts.tents.size(), 1)))) return st;
   }
+  auto upload_set = [&](TileDev& d, const fa::TileSet& t) -> fa_status {
+    fa_status s2;
+    if ((s2 = upload(&d.tinfo, t.tinfo.data(), t.tinfo.size()))) return s2;
+    if ((s2 = upload(&d.tnodes, t.tnodes.data(), t.tnodes.size()))) return s2;
+    if ((s2 = upload(&d.telems, t.telems.data(), t.telems.size()))) return s2;
+    if ((s2 = upload(&d.tconn, t.tconn.data(), t.tconn.size()))) return s2;
+    if ((s2 = upload(&d.tpairs, t.tpairs.data(), t.tpairs.size()))) return s2;
+    return upload(&d.tents, t.tents.data(), std::max<size_t>(t.tents.size(), 1));
+  };
+  if (c->ematK.ok && (st = upload_set(c->ematK, tsK))) return st;
+  if (c->ematF.ok && (st = upload_set(c->ematF, tsF))) return st;
+  if (c->fvec.ok) {
+    if ((st = upload_set(c->fvec, tsV))) return st;
+    if ((st = upload(&c->fvec.eslot, tsV.eslot.data(), tsV.eslot.size()))) return st;
+    if ((st = upload(&c->fvec.nval, tsV.nval.data(), tsV.nval.size()))) return st;
+  }
   const int64_t nipt = nel * sh.nip;
   if (p->model == FA_PHASE_FRACTURE || p->model >= FA_MICRO_PHASE_FRACTURE) {
     for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void**)&c->d_hist[k], std::max<int64_t>(nipt, 1) * sizeof(double)));
@@ -854,6 +959,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[1], nipt, 0.0);
   }
   c->max_parts = std::max(std::max(std::max(std::max(std::max(c->nwg, c->ntile2), c->ngrid_generic), c->npatch), c->ngrid_coop), c->ntile3);
+  c->max_parts = std::max(c->max_parts, std::max(std::max(c->ematK.ntile, c->ematF.ntile), c->fvec.ntile));
   if (p->model == FA_PHASE_FRACTURE_EXTIT || p->model == FA_MICRO_PHASE_FRACTURE_EXTIT)
     HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(c->max_parts, 1)));
   HIP_TRY(hipDeviceSynchronize());
@@ -961,13 +1067,25 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   const bool keep = want_K && (P.keep2 || P.keep3);
   // bitwise reproducibility exists on the ordered row kernel only: the tile / cooperative / generic kernels add f_int
   // (and, the last two, K) with atomics whose order varies from run to run
-  if ((a->flags & FA_DETERMINISTIC) && (!c->rows_path || (a->flags & FA_FORCE_GENERIC)))
+  const TileDev* emat = (a->flags & FA_FORCE_GENERIC) ? nullptr : (a->K_values ? (c->ematK.ok ? &c->ematK : nullptr) : (c->fvec.ok ? &c->fvec : (c->ematF.ok ? &c->ematF : nullptr)));
+  if ((a->flags & FA_DETERMINISTIC) && !emat && (!c->rows_path || (a->flags & FA_FORCE_GENERIC)))
     return fail(FA_ERR_UNSUPPORTED, "FA_DETERMINISTIC needs the row kernel (Triangle3/Gauss1, Quad4, Hex8 on a canonical node-major "
                                     "pattern): this context runs an atomic-scatter kernel");
   int path = c->coop ? fa::PATH_COOP : fa::PATH_GENERIC;
   if (c->rows_path && !(a->flags & FA_FORCE_GENERIC))
     path = (a->flags & FA_DETERMINISTIC) ? fa::PATH_ROWS_ORDERED : (c->patch_path ? fa::PATH_PATCH : (c->pair_path ? fa::PATH_ROWS_PAIR : fa::PATH_ROWS));
   if (c->tile_path && (want_K || c->tile_force_only) && !(a->flags & (FA_FORCE_GENERIC | FA_DETERMINISTIC))) path = fa::PATH_TILES;
+  if (emat) {                                          // element-matrix kernel: no atomics, so it also serves FA_DETERMINISTIC
+    path = (emat == &c->fvec) ? fa::PATH_FVEC : fa::PATH_EMAT;
+    P.eslot = emat->eslot; P.nval = emat->nval; P.fvec_val = emat->lpe;
+    P.tinfo = emat->tinfo; P.tnodes = emat->tnodes; P.telems = emat->telems; P.tconn = emat->tconn;
+    P.tpairs = emat->tpairs; P.tents = emat->tents; P.ntile3 = emat->ntile; P.tile_lds = emat->lds;
+    P.tile_block = emat->block; P.emat_lpe = emat->lpe;
+    P.conn_stride = emat->conn_stride; P.persistent = 0;
+    if (emat->persistent) {
+      P.persistent = 1; P.st_maxn = emat->maxn; P.st_maxe = emat->maxe; P.tile_lds = emat->plds;
+    }
+  }
   if (c->nel == 0) {
     if (P.overwrite) {
       if (want_K) HIP_TRY(hipMemsetAsync(a->K_values, 0, sizeof(double) * c->nnz, st));
@@ -981,6 +1099,13 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   else if (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) { P.ntile = c->nwg; grid = (c->nwg + 7) / 8 * 8; }
   else if (path == fa::PATH_ROWS_PAIR) grid = (c->ntile2 + 7) / 8 * 8;
   else if (path == fa::PATH_TILES) grid = (c->ntile3 + 7) / 8 * 8;
+  else if (path == fa::PATH_EMAT || path == fa::PATH_FVEC) {
+    grid = (emat->ntile + 7) / 8 * 8;
+    if (emat->persistent) {                            // as many workgroups as fit the GPU at once (LDS-bound), a multiple of 8
+      const int per_cu = std::max(1, std::min(4, (160 * 1024) / std::max(emat->plds, 1)));
+      grid = std::min(grid, std::max(8, c->ncu * per_cu / 8 * 8));
+    }
+  }
   else {
     grid = c->coop ? c->ngrid_coop : c->ngrid_generic;
     if (a->flags & FA_FORCE_GENERIC) P.canon = 0;      // testing: per-entry column search
@@ -1008,7 +1133,7 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   if (rc == -1000) return fail(FA_ERR_UNSUPPORTED, "kernel family not built for this shape");
   if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   if (want_err) {
-    const int nparts = (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) ? c->nwg : (path == fa::PATH_ROWS_PAIR ? c->ntile2 : (path == fa::PATH_TILES ? c->ntile3 : grid));
+    const int nparts = (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) ? c->nwg : (path == fa::PATH_ROWS_PAIR ? c->ntile2 : (path == fa::PATH_TILES ? c->ntile3 : ((path == fa::PATH_EMAT || path == fa::PATH_FVEC) ? emat->ntile : grid)));
     hipLaunchKernelGGL(reduce_err_kernel, dim3(1), dim3(256), 0, st, err_part, nparts, a->err_ext);
     HIP_TRY(hipGetLastError());
   }

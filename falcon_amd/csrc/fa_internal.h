@@ -41,7 +41,7 @@ constexpr int lrec_stride(int npe) { return ((2 + npe + (npe + 3) / 4) + 3) / 4 
 constexpr int lrec_stride2(int npe) { return ((3 + npe + (npe + 3) / 4) + 3) / 4 * 4; }
 // per workgroup: n0, n1, first lane t0 (lo), lane count, CSR base (lo, hi), image length, t0 (hi)
 constexpr int kWgInfo = 8;
-enum { PATH_PATCH = 0, PATH_ROWS = 1, PATH_GENERIC = 2, PATH_ROWS_ORDERED = 3, PATH_COOP = 4, PATH_ROWS_PAIR = 5, PATH_TILES = 6 };
+enum { PATH_PATCH = 0, PATH_ROWS = 1, PATH_GENERIC = 2, PATH_ROWS_ORDERED = 3, PATH_COOP = 4, PATH_ROWS_PAIR = 5, PATH_TILES = 6, PATH_EMAT = 7, PATH_FVEC = 8 };
 
 // kernel family: which compute core is instantiated
 enum { FAM_LE = 0, FAM_PF_ISO = 1, FAM_PF_MIEHE = 2 };
@@ -73,6 +73,19 @@ constexpr int tile_stage_bytes(int ndofpn, int block) { return (block / 64) * (6
 // doubles staged per tile node: x, u and (phase-field families) phi; the Ext variants add phi of state0 and of
 // state00 / stateExt_ in an array of their own
 constexpr int tile_node_doubles(int rank, bool pf) { return 2 * rank + (pf ? 1 : 0); }
+
+// element-matrix kernel (fa_emat_impl.h): doubles of one element slot -- the node-pair blocks a <= b of K1 (+ the K4
+// entry), f1 / f2, and K2 / K3 in full when the off-diagonal blocks are kept; odd
+constexpr int emat_slot_doubles(int rank, int npe, bool pf, bool want_K, bool keep) {
+  return ((want_K ? npe * (npe + 1) / 2 * (rank * rank + (pf ? 1 : 0)) : 0) + npe * (rank + (pf ? 1 : 0)) +
+          ((want_K && keep) ? 2 * npe * npe * rank : 0)) | 1;
+}
+
+// persistent kernels: bytes of one LDS staging buffer (fa_emat_impl.h, StageLayout): per node 16 (coordinates) + 32 or 16
+// (state: two 12-byte pieces at 16 bytes each, or one 16-byte piece) + 4 (valence) + 4 (id), per element two history pieces + 8 (connectivity) + 4 (element word) + 4 (rank word)
+constexpr int stage_bytes_host(bool pf, int nip, int maxn, int maxe, bool hist) {
+  return maxn * (16 + (pf ? 32 : 16) + 8) + maxe * ((hist ? 2 * (nip == 4 ? 16 : 4) : 0) + 16);
+}
 
 // cooperative element kernel (higher-order shapes): elements per workgroup so that the LDS slots of the largest
 // family (Miehe with off-diagonal blocks) stay below 64 KB
@@ -116,6 +129,8 @@ struct Params {
   const uint16_t* tconn;     // per tile element: npe indices into the tile's node list
   const uint32_t* tpairs;    // 4 words per pair lane: owned index | position in the row << 16 | elements << 24, entry offset, mirror, pad
   const uint32_t* tents;     // per (pair, shared element): slot | local node a << 16 | local node b << 24
+  const uint32_t* eslot;     // force-vector tiles: per tile element, byte a = rank of the element at its local node a
+  const uint32_t* nval;      // force-vector tiles: per tile node, incident elements (owned nodes)
   const double*  tab;        // shape tables: N[nip][npe], dN[nip][npe][rank], w[nip]
   // ---- vectors (device) ----
   const double*  state;
@@ -130,7 +145,7 @@ struct Params {
   double*        f;
   // ---- sizes / switches ----
   int64_t nnode, nel;
-  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2, ntile3, tile_lds, tile_stage, tile_block, rec_padded;
+  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2, ntile3, tile_lds, tile_stage, tile_block, rec_padded, emat_lpe, fvec_val, conn_stride, st_maxn, st_maxe, persistent;
   int32_t cnt[4];            // entries per neighbour node in a row of dof type i
   int32_t off[4][4];         // offset of column type j inside that group, -1 if not in the pattern
   // ---- constants ----
@@ -152,6 +167,12 @@ int launch_quad8_g3(const Params&, int, bool, bool, int, int, void*);
 int launch_quad8_g2(const Params&, int, bool, bool, int, int, void*);
 int launch_hex20_g3(const Params&, int, bool, bool, int, int, void*);
 int launch_hex20_g2(const Params&, int, bool, bool, int, int, void*);
+
+// element-matrix tile kernel (fa_kernels_emat.hip)
+int launch_emat_quad4_g2(const Params&, int fam, bool want_K, bool keep, int grid, void* stream);
+int launch_emat_tri3_g1 (const Params&, int fam, bool want_K, bool keep, int grid, void* stream);
+int launch_fvec_quad4_g2(const Params&, int fam, int grid, void* stream);
+int launch_fvec_tri3_g1 (const Params&, int fam, int grid, void* stream);
 
 // getStress_ table kernels, one per space dimension (fa_kernels_quad4.hip / fa_kernels_hex8.hip)
 int launch_stress_table_2d(const Params&, int npe, int nip, int plane_stress, double* table, double* weights, void* stream);

@@ -26,6 +26,12 @@
 
 namespace fa {
 
+// The shape tables are never written: read through the constant address space their loads stay scalar (s_load)
+// wherever the index is uniform, even after the kernel's own global stores (history, strain cache); through a plain
+// global pointer they become vector loads with a memory round trip inside the Gauss-point loop.
+typedef const __attribute__((address_space(4))) double* const_dptr;
+typedef const __attribute__((address_space(4))) int32_t* const_iptr;
+
 template <int RANK_, int NPE_, int NIP_>
 struct Shape {
   static constexpr int RANK = RANK_, NPE = NPE_, NIP = NIP_;
@@ -561,25 +567,21 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
 // history (PhaseFractureModel.cpp:629-703; Ext variants PhaseFractureExtModel.cpp:656-758).
 // `ip` may differ from lane to lane.  `write` = this lane is the one that stores the per-point outputs
 // (history, strain cache, errExt_).
+// ip_point_core takes the point's reference-element data (dN/dxi, N, weight) as values, so that a caller can pick
+// them with selects from scalar loads; ip_point reads them from P.tab at index ip.
 template <class SH, int FAM, bool WANT_K, bool KEEP, class SP = SpecRuntime>
-__device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, const ElemData<SH, FAM != FAM_LE>& E,
-                                         double H0, bool write, IpRec<SH, FAM, KEEP>& r, double& err_acc) {
+__device__ __forceinline__ void ip_point_core(const Params& P, int64_t e, int ip, const double (&dn)[SH::NPE][SH::RANK],
+                                              const double (&Nv)[SH::NPE], double wt,
+                                              const ElemData<SH, FAM != FAM_LE>& E,
+                                              double H0, bool write, IpRec<SH, FAM, KEEP>& r, double& err_acc) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, S = SH::S, STR = SH::STR;
   constexpr bool PF = (FAM != FAM_LE);
-  const double* __restrict__ tabN = P.tab;
-  const double* __restrict__ tabD = P.tab + NIP * NPE;
-  const double* __restrict__ tabW = P.tab + NIP * NPE * (1 + RANK);
 
   double J[RANK][RANK];
 #pragma unroll
   for (int i = 0; i < RANK; i++)
 #pragma unroll
     for (int k = 0; k < RANK; k++) J[i][k] = 0.0;
-  double dn[NPE][RANK];
-#pragma unroll
-  for (int a = 0; a < NPE; a++)
-#pragma unroll
-    for (int k = 0; k < RANK; k++) dn[a][k] = tabD[(ip * NPE + a) * RANK + k];
 #pragma unroll
   for (int a = 0; a < NPE; a++)
 #pragma unroll
@@ -608,7 +610,7 @@ __device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, con
     inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
     inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
   }
-  r.w = tabW[ip] * det;
+  r.w = wt * det;
 #pragma unroll
   for (int a = 0; a < NPE; a++)
 #pragma unroll
@@ -654,20 +656,37 @@ __device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, con
     for (int i = 0; i < RANK; i++) r.gphi[i] = 0.0;
 #pragma unroll
     for (int a = 0; a < NPE; a++) {
-      pf += tabN[ip * NPE + a] * E.phi[a];
+      pf += Nv[a] * E.phi[a];
 #pragma unroll
       for (int i = 0; i < RANK; i++) r.gphi[i] += r.g[a][i] * E.phi[a];
     }
     if (SP::model(P) == 2 || SP::model(P) == 3) {
 #pragma unroll
-      for (int a = 0; a < NPE; a++) { pf0 += tabN[ip * NPE + a] * E.phi0[a]; pfX += tabN[ip * NPE + a] * E.phiX[a]; }
+      for (int a = 0; a < NPE; a++) { pf0 += Nv[a] * E.phi0[a]; pfX += Nv[a] * E.phiX[a]; }
     }
     if (SP::model(P) >= 5) {
 #pragma unroll
-      for (int a = 0; a < NPE; a++) pfX += tabN[ip * NPE + a] * E.phiX[a];
+      for (int a = 0; a < NPE; a++) pfX += Nv[a] * E.phiX[a];
     }
   }
   ip_material<SH, FAM, KEEP, SP>(P, ipoint, eps, pf, pf0, pfX, H0, write, r, err_acc);
+}
+
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP = SpecRuntime>
+__device__ __forceinline__ void ip_point(const Params& P, int64_t e, int ip, const ElemData<SH, FAM != FAM_LE>& E,
+                                         double H0, bool write, IpRec<SH, FAM, KEEP>& r, double& err_acc) {
+  constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP;
+  const const_dptr tabN = (const_dptr)P.tab;
+  const const_dptr tabD = tabN + NIP * NPE;
+  const const_dptr tabW = tabN + NIP * NPE * (1 + RANK);
+  double dn[NPE][RANK], Nv[NPE];
+#pragma unroll
+  for (int a = 0; a < NPE; a++) {
+    Nv[a] = tabN[ip * NPE + a];
+#pragma unroll
+    for (int k = 0; k < RANK; k++) dn[a][k] = tabD[(ip * NPE + a) * RANK + k];
+  }
+  ip_point_core<SH, FAM, WANT_K, KEEP, SP>(P, e, ip, dn, Nv, tabW[ip], E, H0, write, r, err_acc);
 }
 
 // Rows of local node la from one Gauss-point record.  Nip[b] = N_b(ip).
@@ -815,7 +834,7 @@ __device__ __forceinline__ void compute_rowblock(const Params& P, int64_t e, int
     ip_point<SH, FAM, WANT_K, KEEP, SP>(P, e, ip, E, H0, owned && ((ip % NPE) == la), r, err_acc);
     double Nip[NPE];
 #pragma unroll
-    for (int b = 0; b < NPE; b++) Nip[b] = P.tab[ip * NPE + b];
+    for (int b = 0; b < NPE; b++) Nip[b] = ((const_dptr)P.tab)[ip * NPE + b];
     accum_rows<SH, FAM, WANT_K, KEEP>(P, r, la, Nip, R);
   }
 }
@@ -1249,7 +1268,11 @@ __device__ __forceinline__ void swap_rec(const IpRec<SH, FAM, KEEP>& m, IpRec<SH
 #ifndef FA_PAIR_ATTR
 #define FA_PAIR_ATTR __attribute__((amdgpu_waves_per_eu(2)))
 #endif
-template <class SH, int FAM, bool WANT_K, bool KEEP, class SP>
+// LDSTAB: the lane's shape-table row comes from an LDS copy (per-lane address, a broadcast read); otherwise both
+// candidates come from scalar loads and are picked with selects.  Measured on cfg3 / cfg2 (MI355X, round 2): the LDS
+// copy wins for the u-phi matrix pass in overwrite mode (4.55 against 4.89 ms), the selects win for the accumulate
+// mode (7.06 / 7.40), with off-diagonal blocks (4.51 / 4.95) and for the elastic model (2.21 / 2.32).
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP, bool LDSTAB>
 __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(const Params P) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, HALF = SH::NIP / 2, kBlock = SH::BLOCK, kLdsDoubles = SH::LDS;
   constexpr bool PF = (FAM != FAM_LE);
@@ -1258,11 +1281,21 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
   __shared__ __attribute__((aligned(16))) double sKbuf[WANT_K ? kLdsDoubles + 2 : 2];
   __shared__ double sF[kBlock * NDOF];
   __shared__ double sErr[kBlock / 64];
+  // shape tables in LDS, one row per Gauss point: dN/dxi [NPE][RANK], N [NPE], w, padded to an even number of doubles.
+  // A lane's point depends on its half, so table reads are per-lane: from LDS they cost a broadcast read instead of a
+  // trip to the vector memory pipeline (or 2 selects per value from scalar loads: measured slower in this VALU-bound kernel)
+  constexpr int TROW = (NPE * (RANK + 1) + 1 + 1) & ~1;
+  __shared__ __attribute__((aligned(16))) double sTabL[LDSTAB ? NIP * TROW : 2];
 
   const int tid = threadIdx.x;
 #ifdef FA_TRACE
   long long tr[8]; tr[0] = __builtin_readcyclecounter();
 #endif
+  if (LDSTAB && tid < NIP * TROW) {
+    const int ipt = tid / TROW, q = tid - ipt * TROW;
+    const const_dptr tN = (const_dptr)P.tab, tD = tN + NIP * NPE, tW = tN + NIP * NPE * (1 + RANK);
+    sTabL[tid] = (q < NPE * RANK) ? tD[ipt * NPE * RANK + q] : ((q < NPE * (RANK + 1)) ? tN[ipt * NPE + (q - NPE * RANK)] : ((q == NPE * (RANK + 1)) ? tW[ipt] : 0.0));
+  }
   const int per = (int)gridDim.x >> 3;                 // XCD bands as in assemble_rows
   const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
   if (tile >= P.ntile2) return;
@@ -1335,15 +1368,35 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
       double H0 = 0.0;
 #pragma unroll
       for (int q = 0; q < HALF; q++) if (q == k) H0 = H0v[q];
-      ip_point<SH, FAM, WANT_K, KEEP, SP>(P, e, ip, E, H0, (fl >> (2 + k)) & 1u, r, err_acc);
-      double Nip[NPE];
+      // reference-element data of the lane's own point (k or HALF + k) and of its partner's, from the LDS copy
+      double dn[NPE][RANK], Nv[NPE], No[NPE], wt;
+      if constexpr (LDSTAB) {
+        const double* __restrict__ row = sTabL + ip * TROW;
+        const double* __restrict__ rowo = sTabL + ipo * TROW;
 #pragma unroll
-      for (int b = 0; b < NPE; b++) Nip[b] = P.tab[ip * NPE + b];
-      accum_rows<SH, FAM, WANT_K, KEEP>(P, r, la, Nip, R);
+        for (int a = 0; a < NPE; a++) {
+#pragma unroll
+          for (int d = 0; d < RANK; d++) dn[a][d] = row[a * RANK + d];
+          Nv[a] = row[NPE * RANK + a]; No[a] = rowo[NPE * RANK + a];
+        }
+        wt = row[NPE * (RANK + 1)];
+      } else {
+        const const_dptr tN = (const_dptr)P.tab, tD = tN + NIP * NPE, tW = tN + NIP * NPE * (1 + RANK);
+        const int i0 = k, i1 = HALF + k;
+#pragma unroll
+        for (int a = 0; a < NPE; a++) {
+          const double n0 = tN[i0 * NPE + a], n1 = tN[i1 * NPE + a];
+          Nv[a] = half ? n1 : n0; No[a] = half ? n0 : n1;
+#pragma unroll
+          for (int d = 0; d < RANK; d++) { const double d0 = tD[(i0 * NPE + a) * RANK + d], d1 = tD[(i1 * NPE + a) * RANK + d]; dn[a][d] = half ? d1 : d0; }
+        }
+        const double w0 = tW[i0], w1 = tW[i1];
+        wt = half ? w1 : w0;
+      }
+      ip_point_core<SH, FAM, WANT_K, KEEP, SP>(P, e, ip, dn, Nv, wt, E, H0, (fl >> (2 + k)) & 1u, r, err_acc);
+      accum_rows<SH, FAM, WANT_K, KEEP>(P, r, la, Nv, R);
       swap_rec<SH, FAM, KEEP>(r, rp);
-#pragma unroll
-      for (int b = 0; b < NPE; b++) Nip[b] = P.tab[ipo * NPE + b];
-      accum_rows<SH, FAM, WANT_K, KEEP>(P, rp, la, Nip, R);
+      accum_rows<SH, FAM, WANT_K, KEEP>(P, rp, la, No, R);
     }
   }
 #ifdef FA_TRACE
@@ -1460,7 +1513,10 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
     else {
       auto go = [&](auto spec) {
         using SP = decltype(spec);
-        hipLaunchKernelGGL((assemble_rows_pair<SH, FAM, WANT_K, KEEP, SP>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
+        if constexpr (WANT_K && FAM == FAM_PF_ISO && !KEEP) {
+          if (P.overwrite) { hipLaunchKernelGGL((assemble_rows_pair<SH, FAM, WANT_K, KEEP, SP, true>), dim3(grid), dim3(SH::BLOCK), 0, st, P); return; }
+        }
+        hipLaunchKernelGGL((assemble_rows_pair<SH, FAM, WANT_K, KEEP, SP, false>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
       };
       if constexpr (FAM == FAM_LE) go(SpecFixed<0, 0, 0>{});
       else if constexpr (FAM == FAM_PF_ISO) {

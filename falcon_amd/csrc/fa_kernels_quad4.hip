@@ -3,6 +3,8 @@
 
 namespace fa {
 int launch_quad4_g2(const Params& P, int fam, bool want_K, bool keep, int path, int grid, void* stream) {
+  if (path == PATH_FVEC) return launch_fvec_quad4_g2(P, fam, grid, stream);
+  if (path == PATH_EMAT) return launch_emat_quad4_g2(P, fam, want_K, keep, grid, stream);
   if (path == PATH_TILES) return launch_tiles_shape<Shape<2,4,4>>(P, fam, want_K, keep, grid, stream);
   return launch_shape<Shape<2,4,4>>(P, fam, want_K, keep, path, grid, stream);
 }

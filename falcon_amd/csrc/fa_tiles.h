@@ -16,7 +16,30 @@ struct TileSet {
   std::vector<uint32_t> tpairs;          // 4 words per pair lane: owned index | row position << 16 | elements << 24, entry offset,
                                          // mirror (second owned index | its row position << 16 | bit 31) or 0, pad
   std::vector<uint32_t> tents;           // one word per (pair, shared element)
+  std::vector<uint32_t> eslot;           // fvec mode: per tile element, byte a = rank of the element among the incident
+                                         // elements of its local node a (element-ascending)
+  std::vector<uint32_t> nval;            // fvec mode: per tile node, the number of incident elements (owned nodes only)
+  int max_all = 0, max_el = 0, max_own = 0;   // largest node / element / owned-node count of a tile
+  int conn_stride = 0;                   // entries of tconn per tile element (npe, or 4 when padded)
   double point_redundancy = 0.0;         // tile elements / elements: how often a Gauss point is evaluated per pass
+};
+
+// What the element-matrix kernel (fa_emat_impl.h) asks of the tiling on top of the tile kernel's:
+struct TileOpts {
+  int slot_doubles = 0;     // > 0: doubles of one element slot (instead of nip Gauss-point records of rec_doubles)
+  int max_el = 0;           // > 0: at most this many elements per tile (phase 1 of the element-matrix kernel is one pass)
+  int max_own = 0;          // > 0: at most this many owned nodes per tile
+  bool diag_only = false;   // pair lanes only for (a, a): force-only passes sum f_int over a node's elements
+  int order = -1;           // pair-lane order: 0 count-sorted with (a,b)/(b,a) sharing a lane, 1 row order with the
+                            // diagonal blocks first, 2 plain (node, neighbour) order; -1: from `row_order`
+  bool no_tab = false;      // no shape tables in LDS
+  bool no_f_image = false;  // no f image in LDS
+  int own_doubles = 0;      // extra doubles of LDS per owned node
+  int max_all = 0;          // > 0: at most this many nodes (owned + halo) per tile
+  bool conn_pad4 = false;   // tconn rows padded to 4 entries (8 bytes per element: the persistent kernels fetch them with
+                            // two 4-byte LDS-DMA loads)
+  int fvec = 0;             // > 0: force-vector mode (fa_emat_impl.h, assemble_fvec): no element slots, no pair lanes; per
+                            // element the slot ranks of its nodes, per owned node its valence (<= fvec)
 };
 
 // Nodes are sorted along a Morton curve of their grid-quantised coordinates and cut into tiles whose staged data
@@ -27,6 +50,7 @@ struct TileSet {
 // Returns false when the mesh cannot be tiled (a single node's elements exceed the budget, counters overflow).
 bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndofpn, const double* coords,
                  const int32_t* conn, const int32_t* n2e_ptr, const int32_t* n2e_ent, const int64_t* nb_ptr,
-                 const int32_t* nb, int rec_doubles, int node_doubles, int lds_budget, int block, bool row_order, TileSet& out);
+                 const int32_t* nb, int rec_doubles, int node_doubles, int lds_budget, int block, bool row_order, TileSet& out,
+                 const TileOpts& opts = TileOpts());
 
 }  // namespace fa

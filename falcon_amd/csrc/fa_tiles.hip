@@ -47,12 +47,14 @@ inline uint64_t spread2(uint64_t v) {                  // 31 bits -> every secon
 
 struct Cutter {                                        // greedy cut of the sorted node sequence
   int64_t nnode, nel; int npe, nip, ndofpn, rec_doubles, node_doubles, lds_budget, tabn, extra_bytes;
+  TileOpts opts;
   const int32_t* conn; const int32_t* n2e_ptr; const int32_t* n2e_ent; const int64_t* nb_ptr;
   const std::vector<int32_t>& order; const std::vector<uint64_t>& key;
   std::vector<int32_t> estamp, nstamp;
 
   int64_t bytes(int64_t n_el, int64_t n_all, int64_t n_own) const {
-    return 8 * (n_el * tile_slot_doubles(nip, rec_doubles) + n_all * node_doubles + n_own * (ndofpn + 2) + tabn) + 2 * n_el * npe + 16 + extra_bytes;
+    const int64_t slot = opts.fvec > 0 ? 0 : (opts.slot_doubles > 0 ? opts.slot_doubles : tile_slot_doubles(nip, rec_doubles));
+    return 8 * (n_el * slot + n_all * node_doubles + n_own * (opts.own_doubles + (opts.no_f_image ? 0 : ndofpn) + 2) + (opts.no_tab ? 0 : tabn)) + 2 * n_el * (opts.conn_pad4 ? 4 : npe) + 16 + extra_bytes;
   }
   // Tiles end where the Morton cell of 2^L codes ends (once half full) or where the LDS budget / counters say so.
   // Returns false if one node alone does not fit.  starts: first position of every tile in `order` (+ sentinel).
@@ -90,9 +92,12 @@ struct Cutter {                                        // greedy cut of the sort
         }
         const int64_t deg = nb_ptr[n + 1] - nb_ptr[n], val = n2e_ptr[n + 1] - n2e_ptr[n];
         const bool fits = bytes(n_el + add_el, n_all + add_all, n_own + 1) <= lds_budget && n_all + add_all <= 65535 &&
-                          n_el + add_el <= 65535 && n_pairs + deg <= 2000000 && val <= 255;
+                          n_el + add_el <= 65535 && n_pairs + deg <= 2000000 && val <= 255 &&
+                          (opts.max_el <= 0 || n_el + add_el <= opts.max_el) && (opts.max_own <= 0 || n_own + 1 <= opts.max_own) &&
+                          (opts.fvec <= 0 || val <= opts.fvec) && (opts.max_all <= 0 || n_all + add_all <= opts.max_all);
         if (fits) {
-          n_own++; n_all += add_all; n_el += add_el; n_pairs += deg; n_ents += val * npe;
+          n_own++; n_all += add_all; n_el += add_el;
+          if (opts.fvec <= 0) { n_pairs += opts.diag_only ? 1 : deg; n_ents += opts.diag_only ? val : val * npe; }
           break;
         }
         for (int32_t e : undo_e) estamp[e] = -1;
@@ -111,7 +116,8 @@ struct Cutter {                                        // greedy cut of the sort
 
 bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndofpn, const double* coords,
                  const int32_t* conn, const int32_t* n2e_ptr, const int32_t* n2e_ent, const int64_t* nb_ptr,
-                 const int32_t* nb, int rec_doubles, int node_doubles, int lds_budget, int block, bool row_order, TileSet& T) {
+                 const int32_t* nb, int rec_doubles, int node_doubles, int lds_budget, int block, bool row_order, TileSet& T,
+                 const TileOpts& opts) {
   if (nnode <= 0 || nel <= 0 || npe > 255) return false;
   // ---- spatial order: Morton code of the coordinates quantised to the mean node spacing ----
   double lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
@@ -145,7 +151,8 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
   code.clear(); code.shrink_to_fit();
 
   const int tabn = nip * npe * (1 + rank) + nip;
-  Cutter C{ nnode, nel, npe, nip, ndofpn, rec_doubles, node_doubles, lds_budget, tabn, row_order ? tile_stage_bytes(ndofpn, block) : 0, conn, n2e_ptr, n2e_ent, nb_ptr, order, key, {}, {} };
+  const int order_mode = opts.order >= 0 ? opts.order : (row_order ? 1 : 0);
+  Cutter C{ nnode, nel, npe, nip, ndofpn, rec_doubles, node_doubles, lds_budget, tabn, (order_mode != 0 && !opts.diag_only) ? tile_stage_bytes(ndofpn, block) : 0, opts, conn, n2e_ptr, n2e_ent, nb_ptr, order, key, {}, {} };
   // ---- cell size: the Morton cell (or none: tiles filled to the budget) that evaluates the fewest elements per owned node ----
   std::vector<int64_t> starts; int64_t by_limit = 0;
   const int64_t sample = std::min<int64_t>(nnode, 200000);
@@ -177,13 +184,21 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
     max_bytes = std::max(max_bytes, C.bytes(c[2], c[1], c[0]));
   }
   const int64_t lim = 0x7FFFFFF0LL;
-  if (o_node[ntile] > lim || o_el[ntile] * npe > lim || o_pair[ntile] * 4 > lim || o_ent[ntile] > lim) return false;
+  if (o_node[ntile] > lim || o_el[ntile] * 4 > lim || o_pair[ntile] * 4 > lim || o_ent[ntile] > lim) return false;
   T.ntile = (int)ntile; T.lds_bytes = (int)max_bytes;
   T.tinfo.assign((size_t)ntile * kTileInfo, 0);
   T.tnodes.assign((size_t)o_node[ntile], 0); T.telems.assign((size_t)o_el[ntile], 0);
-  T.tconn.assign((size_t)o_el[ntile] * npe, 0);
+  const int cs = opts.conn_pad4 ? 4 : npe;
+  if (opts.conn_pad4 && npe > 4) return false;
+  T.conn_stride = cs;
+  T.tconn.assign((size_t)o_el[ntile] * cs, 0);
+  for (int64_t t = 0; t < ntile; t++) {
+    const int32_t* c = counts.data() + t * 5;
+    T.max_own = std::max(T.max_own, c[0]); T.max_all = std::max(T.max_all, c[1]); T.max_el = std::max(T.max_el, c[2]);
+  }
   T.tpairs.assign((size_t)o_pair[ntile] * 4, 0); T.tents.assign((size_t)o_ent[ntile], 0);
   T.point_redundancy = (double)o_el[ntile] / (double)nel;
+  if (opts.fvec > 0) { T.eslot.assign((size_t)o_el[ntile], 0); T.nval.assign((size_t)o_node[ntile], 0); }
 
   // ---- fill ----
   par_for(ntile, [&](int64_t tb, int64_t te) {
@@ -218,12 +233,28 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
       for (size_t i = 0; i < halo.size(); i++) { tn[n_own + i] = halo[i]; lookup.emplace_back(halo[i], n_own + (int32_t)i); }
       std::sort(lookup.begin(), lookup.end());
       int32_t* tel = T.telems.data() + o_el[t];
-      uint16_t* tc = T.tconn.data() + o_el[t] * npe;
+      uint16_t* tc = T.tconn.data() + o_el[t] * cs;
       for (size_t s = 0; s < els.size(); s++) {
         const int32_t* cn = conn + (int64_t)els[s] * npe;
         const int first = find_local(cn[0]);
         tel[s] = els[s] | ((first >= 0 && first < n_own) ? (int32_t)0x80000000 : 0);
-        for (int a = 0; a < npe; a++) tc[s * npe + a] = (uint16_t)find_local(cn[a]);
+        for (int a = 0; a < npe; a++) tc[s * cs + a] = (uint16_t)find_local(cn[a]);
+      }
+      if (opts.fvec > 0) {
+        // force-vector mode: rank of every tile element in the (element-ascending) incident lists of its nodes
+        uint32_t* es = T.eslot.data() + o_el[t];
+        uint32_t* nv = T.nval.data() + o_node[t];
+        for (int ia = 0; ia < n_own; ia++) {
+          const int32_t a = own[ia];
+          nv[ia] = (uint32_t)(n2e_ptr[a + 1] - n2e_ptr[a]);
+          for (int32_t u = n2e_ptr[a]; u < n2e_ptr[a + 1]; u++) {
+            const int32_t el = n2e_ent[u] / npe, la = n2e_ent[u] - el * npe;
+            const size_t slot = (size_t)(std::lower_bound(els.begin(), els.end(), el) - els.begin());
+            es[slot] |= (uint32_t)(u - n2e_ptr[a]) << (8 * la);
+          }
+        }
+        ti[6] = 0;
+        continue;
       }
       // pairs (owned node, neighbour) with the elements that hold both, element-ascending
       pt.clear(); ent.clear();
@@ -234,7 +265,8 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
           const int32_t b = nb[nb_ptr[a] + k];
           PairTmp q; q.first = (uint32_t)ent.size(); q.cnt = 0; q.w2 = 0;
           const int ib = find_local(b);
-          if (!row_order && ib >= 0 && ib < n_own && ib != ia) {   // both owned: one lane for (a, b) and (b, a)
+          if (opts.diag_only && ib != ia) continue;
+          if (order_mode == 0 && ib >= 0 && ib < n_own && ib != ia) {   // both owned: one lane for (a, b) and (b, a)
             if (ib < ia) continue;
             const int32_t* lo2 = nb + nb_ptr[b]; const int32_t* hi2 = nb + nb_ptr[b + 1];
             const uint32_t k2 = (uint32_t)(std::lower_bound(lo2, hi2, a) - lo2);
@@ -253,10 +285,13 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
           }
           q.w0 = (uint32_t)ia | ((uint32_t)k << 16) | (q.cnt << 24);
           q.diag = (ib == ia);
+          if (q.diag) q.w2 |= 0x40000000u;             // bit 30: diagonal block (the element-matrix kernel sums f_int there)
           pt.push_back(q);
         }
       }
-      if (row_order) {
+      if (order_mode == 2) {
+        // plain (node, neighbour) order: consecutive lanes hold consecutive chunks of the same CSR rows
+      } else if (order_mode == 1) {
         // the diagonal blocks first (they hold the most elements), then the others in (node, neighbour) order: the
         // lanes of a wave then write consecutive chunks of the same CSR rows
         std::stable_sort(pt.begin(), pt.end(), [&](const PairTmp& x, const PairTmp& y) {

@@ -89,3 +89,143 @@ def element_pf(x, N, dN, w, u, phi, H0, mat, frac, keep):
         f1 += wip * B.T @ sig
         f2 += wip * (Nip * (gc / (cw * l0) * dw + dg * psi) + (2 * gc * l0 / cw) * (g @ g.T) @ phi)
     return K1, K2, K3, K4, f1, f2, Hn
+
+
+# ---- MiehePhaseMaterial with numpy.linalg.eigh (NOT the cyclic Jacobi the oracle and the kernels share) ----
+# Full 3x3x3x3 tensors exactly as the reference writes them: getposProj_ (MiehePhaseMaterial.cpp:342-406),
+# update (:200-258), otimes / otimesu / otimesl / doubleDot (TensorUtils.cpp:73-231), tensor2voigt (:304-398, with
+# its duplicated-term shear entries restated verbatim), voigt2tensorStrain (:467-492), tensor2voigtStress (:436-460).
+def _voigt_pairs(n):
+    return [(0, 0), (1, 1), (2, 2), (0, 1)] + ([(1, 2), (2, 0)] if n == 6 else [])
+
+
+def tensor2voigt(A, n):
+    M = np.zeros((n, n))
+    pr = _voigt_pairs(n)
+    for I, (i, j) in enumerate(pr):
+        for J, (k, l) in enumerate(pr):
+            if I < 3 and J < 3:
+                M[I, J] = A[i, j, k, l]
+            elif I >= 3 and J < 3:
+                M[I, J] = 0.5 * (A[i, j, k, l] + A[j, i, k, l])
+            elif I < 3 and J >= 3:
+                M[I, J] = 0.5 * (A[i, j, k, l] + A[i, j, l, k])
+            elif n == 4:
+                M[I, J] = 0.25 * (A[0, 1, 0, 1] + A[1, 0, 0, 1] + A[0, 1, 1, 0] + A[1, 0, 1, 0])
+            else:
+                # TensorUtils.cpp:366-397 as written: some entries repeat two terms instead of using all four
+                dup = {(3, 3): [(0, 1, 0, 1), (1, 0, 1, 0), (0, 1, 0, 1), (1, 0, 1, 0)],
+                       (4, 3): [(1, 2, 0, 1), (2, 1, 1, 0), (2, 1, 0, 1), (1, 2, 1, 0)],
+                       (5, 3): [(0, 2, 0, 1), (2, 0, 1, 0), (2, 0, 0, 1), (0, 2, 1, 0)],
+                       (3, 4): [(0, 1, 1, 2), (1, 0, 2, 1), (0, 1, 1, 2), (1, 0, 2, 1)],
+                       (4, 4): [(1, 2, 1, 2), (2, 1, 2, 1), (2, 1, 1, 2), (1, 2, 2, 1)],
+                       (5, 4): [(0, 2, 1, 2), (2, 0, 2, 1), (2, 0, 1, 2), (0, 2, 2, 1)],
+                       (3, 5): [(0, 1, 0, 2), (1, 0, 2, 0), (0, 1, 0, 2), (1, 0, 2, 0)],
+                       (4, 5): [(1, 2, 0, 2), (2, 1, 2, 0), (2, 1, 0, 2), (1, 2, 2, 0)],
+                       (5, 5): [(0, 2, 0, 2), (2, 0, 2, 0), (2, 0, 0, 2), (0, 2, 2, 0)]}[(I, J)]
+                M[I, J] = 0.25 * sum(A[t] for t in dup)
+    return M
+
+
+def miehe(rank, E, nu, eps, g, eigh=np.linalg.eigh):
+    """returns sigma, D, Psi, sigma+ (Voigt, STRAIN_COUNTS[rank] entries) and the eigenvalues."""
+    n = eps.size
+    K = E / (3 * (1 - 2 * nu)); G = E / (2 * (1 + nu)); lam = K - 0.666666667 * G     # MiehePhaseMaterial.cpp:97-99
+    T = np.zeros((3, 3))
+    T[0, 0], T[1, 1], T[2, 2] = eps[0], eps[1], eps[2]
+    T[0, 1] = T[1, 0] = 0.5 * eps[3]
+    if n == 6:
+        T[1, 2] = T[2, 1] = 0.5 * eps[4]; T[2, 0] = T[0, 2] = 0.5 * eps[5]
+    val, vec = eigh(T)
+    epos = 0.5 * (val + np.abs(val)); diag = (val > 0.0).astype(float)
+    P = np.zeros((3, 3, 3, 3))
+    M = [np.outer(vec[:, a], vec[:, a]) for a in range(3)]
+    for a in range(3):
+        P += np.einsum("ij,kl->ijkl", M[a], M[a]) * diag[a]
+    for a in range(3):
+        for b in range(a):
+            Gab = np.einsum("ik,jl->ijkl", M[a], M[b]) + np.einsum("il,jk->ijkl", M[a], M[b])
+            Gba = np.einsum("ik,jl->ijkl", M[b], M[a]) + np.einsum("il,jk->ijkl", M[b], M[a])
+            if abs(val[a] - val[b]) <= 1e-13:
+                th = 0.5 * (diag[a] + diag[b]) / 2.0
+            else:
+                th = 0.5 * (epos[a] - epos[b]) / (val[a] - val[b])
+            P += th * (Gab + Gba)
+    I2 = np.eye(3)
+    I4 = 0.5 * (np.einsum("ik,jl->ijkl", I2, I2) + np.einsum("il,jk->ijkl", I2, I2))
+    N4 = I4 - P
+    Tp = np.einsum("ijkl,kl->ij", P, T); Tn = T - Tp
+    tr = np.trace(T)
+    trp = 0.5 * (tr + abs(tr)); trn = 0.5 * (tr - abs(tr))
+    sp_t = lam * trp * I2 + 2 * G * Tp; sn_t = lam * trn * I2 + 2 * G * Tn
+    tv = lambda A: np.array([A[0, 0], A[1, 1], A[2, 2], 0.5 * (A[0, 1] + A[1, 0])] +
+                            ([0.5 * (A[1, 2] + A[2, 1]), 0.5 * (A[0, 2] + A[2, 0])] if n == 6 else []))
+    sP, sN = tv(sp_t), tv(sn_t)
+    psi = 0.5 * lam * trp ** 2 + G * np.einsum("ij,ij->", Tp, Tp)
+    sgn = 0.0 if tr < 0.0 else 1.0                                # heavisideP(0) = 1 (MathUtils.cpp:33-36)
+    II = np.einsum("ij,kl->ijkl", I2, I2)
+    jac = g * (2 * G * P + lam * sgn * II) + (2 * G * N4 + lam * (1 - sgn) * II)
+    return g * sP + sN, tensor2voigt(jac, n), psi, sP, val
+
+
+def degrade(pf, p, a1, a2, a3, floor):
+    gn = (1 - pf) ** p; gd = gn + a1 * pf + a1 * a2 * pf ** 2 + a1 * a2 * a3 * pf ** 3
+    dgn = -p * (1 - pf) ** (p - 1); dgd = dgn + a1 + 2 * a1 * a2 * pf + 3 * a1 * a2 * a3 * pf ** 2
+    ddgn = p * (p - 1) * (1 - pf) ** (p - 2); ddgd = ddgn + 2 * a1 * a2 + 6 * a1 * a2 * a3 * pf
+    dg = (dgn * gd - gn * dgd) / gd ** 2
+    ddg = ((ddgn * gd - gn * ddgd) * gd - 2 * (dgn * gd - gn * dgd) * dgd) / gd ** 3
+    return gn / gd + floor, dg, ddg
+
+
+def element_ext(x, N, dN, w, u, phi, phi0, phiX, dt, dt0, mat, frac, psi0, beta, extit):
+    """PhaseFractureExtModel::getMatrix_ (PhaseFractureExtModel.cpp:640-774) / ...ExtItModel (:660-797): degradation
+    at the extrapolated phase field, Psi = max(Psi, Psi0), K3 without the loading flag, no K2, penalty on phi0 - phi.
+    phiX = state00 (Ext) or stateExt_ (ExtIt).  Returns K1, K3, K4, f1, f2, errExt."""
+    npe, rank = x.shape
+    nd = rank * npe
+    K1 = np.zeros((nd, nd)); K3 = np.zeros((npe, nd)); K4 = np.zeros((npe, npe))
+    f1 = np.zeros(nd); f2 = np.zeros(npe); err = 0.0
+    gc, l0, cw, eta, p, a1, a2, a3 = frac
+    for ip in range(len(w)):
+        J = x.T @ dN[ip]
+        g = dN[ip] @ np.linalg.inv(J)
+        wip = w[ip] * np.linalg.det(J)
+        B = B_matrix(g)
+        eps = B @ u
+        Nip = N[ip]
+        pf = Nip @ phi; pf0 = Nip @ phi0
+        if extit:
+            pfEx = Nip @ phiX
+            err += (pf - pfEx) ** 2
+        elif dt0 < 1e-15:
+            pfEx = pf0
+        else:
+            pfEx = -(Nip @ phiX) * dt / dt0 + pf0 * (dt + dt0) / dt0
+        pfEx = min(max(pfEx, 0.0), 1.0)
+        gEx = degrade(pfEx, p, a1, a2, a3, 1e-7)[0]
+        _, dg, ddg = degrade(pf, p, a1, a2, a3, 1e-7)
+        dw = eta + 2 * (1 - eta) * pf; ddw = 2 * (1 - eta)
+        sig, D, psi, sp = mat(eps, gEx)
+        psi = max(psi, psi0)
+        K1 += wip * B.T @ D @ B
+        K4 += wip * ((gc / (cw * l0) * ddw + ddg * psi) * np.outer(Nip, Nip) + (2 * gc * l0 / cw) * g @ g.T)
+        K3 += wip * dg * np.outer(Nip, sp @ B)
+        f1 += wip * B.T @ sig
+        f2 += wip * (Nip * (gc / (cw * l0) * dw + dg * psi) + (2 * gc * l0 / cw) * (g @ g.T) @ phi)
+        if pf0 - pf > 1e-15:
+            K4 += wip * gc / (cw * l0) * beta * np.outer(Nip, Nip)
+            f2 -= wip * gc / (cw * l0) * beta * (pf0 - pf) * Nip
+    return K1, K3, K4, f1, f2, err
+
+
+def micro_newton(psi, target, d, frac, alpha):
+    """Local damage of the micromorphic model (MicroPhaseFractureModel.cpp:697-732): Newton on
+    Res(d) = g'(d) Psi + gc/(cw l0) w'(d) + alpha (d - target), |Res| <= 1e-4 or 100 iterations."""
+    gc, l0, cw, eta, p, a1, a2, a3 = frac
+    for it in range(101):
+        _, dg, ddg = degrade(d, p, a1, a2, a3, 0.0)
+        res = dg * psi + gc / (cw * l0) * (eta + 2 * (1 - eta) * d) + alpha * (d - target)
+        jac = ddg * psi + gc / (cw * l0) * 2 * (1 - eta) + alpha
+        if abs(res) <= 1e-4 or it == 100:
+            return d, dg, ddg
+        d -= res / jac
