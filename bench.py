@@ -3,9 +3,12 @@
 
 A "step" is one GET_MATRIX0 pass (tangent stiffness K into the CSR value array + internal force f_int)
 over the whole synthetic mesh, inputs resident in HBM.  N=1 workload = BASELINE.json configs[2]
-("cfg3": 4000x4000 Q4, coupled u-phi phase-field fracture, AT2, AmorPhase).  N>1: weak
-scaling, one 4000x(4000) strip per GPU stacked in y, interface f_int entries summed with the
-neighbouring ranks over RCCL (falcon_amd/distributed.py); value = all ranks' elements / max time.
+("cfg3": 4000x4000 Q4, coupled u-phi phase-field fracture, AT2, AmorPhase).  N>1: the mesh is cut
+into N blocks of element layers along its last axis (strips of the Quad4 meshes, slabs of the Hex8 cube;
+falcon_amd/distributed.py), one per GPU; every step ends with the interface exchange over RCCL -- the f_int
+halo-sum and, with --k-halo reduce, the interface rows of K sent to their owner (the lower rank).
+--scaling weak (default): every GPU gets a full-size block (N x the BASELINE mesh in total); --scaling strong:
+the one BASELINE mesh is divided among the GPUs.  value = all ranks' elements / max time over ranks.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5|cfg5g2|cfg3micro] [--n SIZE]
                     [--material amor|miehe|bourdin] [--keep-off-diags] [--mode ...] [--pattern ...] [--force-only]
@@ -30,7 +33,7 @@ def algorithmic_bytes(nnz_written, ndof, nnode, rank, npe, nel, nip, phase_field
     return b
 
 
-def workload(name, n, capi, material="amor", keep=False):
+def workload(name, n, capi, material="amor", keep=False, dims=None):
     mat = {"amor": capi.AMOR_PHASE, "miehe": capi.MIEHE_PHASE, "bourdin": capi.BOURDIN_PHASE}[material]
     mname = {"amor": "AmorPhase", "miehe": "MiehePhase", "bourdin": "BourdinPhase"}[material]
     if name == "cfg2":
@@ -53,17 +56,20 @@ def workload(name, n, capi, material="amor", keep=False):
                     written_per_pair=9 if keep else 5,
                     kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=keep, beta=250.0))
     if name == "cfg4":
-        n = n or 200
-        return dict(desc=f"cfg4: {n}^3 hex8 phase-field fracture cube, AT2, {mname}", shape=capi.HEX8_G2,
-                    model=capi.PHASE_FRACTURE, material=mat, dims=(n, n, n), h=1.0 / n,
+        n = n or 200                                    # BASELINE: 8 M elements = 200^3
+        d3 = dims or (n, n, n)
+        return dict(desc=f"cfg4: {d3[0]}x{d3[1]}x{d3[2]} hex8 phase-field fracture cube, AT2, {mname}, "
+                         f"keepOffDiags={'true' if keep else 'false'}", shape=capi.HEX8_G2,
+                    model=capi.PHASE_FRACTURE, material=mat, dims=d3, h=1.0 / max(d3),
                     written_per_pair=16 if keep else 10,
                     kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=keep))
     if name in ("cfg5", "cfg5g2"):
-        n = n or 64
+        d3 = dims or ((n, n, n) if n else (125, 125, 128))   # BASELINE: 2 M elements = 125 x 125 x 128
         g3 = name == "cfg5"
-        return dict(desc=f"cfg5: {n}^3 hex20 linear-elastic block (Hooke), Gauss{'3' if g3 else '2'}^3",
+        return dict(desc=f"cfg5: {d3[0]}x{d3[1]}x{d3[2]} hex20 linear-elastic block (Hooke; the reference has no Mises material), "
+                         f"Gauss{'3' if g3 else '2'}^3",
                     shape=capi.HEX20_G3 if g3 else capi.HEX20_G2, model=capi.LINEAR_ELASTICITY, material=capi.HOOKE,
-                    dims=(n, n, n), h=1.0 / n, written_per_pair=9, kw=dict(young=210e3, poisson=0.3))
+                    dims=d3, h=1.0 / max(d3), written_per_pair=9, kw=dict(young=210e3, poisson=0.3))
     if name in ("quad8", "quad8g2", "tri6", "tri3", "tri3g3"):   # higher-order 2-D shapes, phase-field fracture like cfg3
         n = n or 1000
         shape, gen, sname = {"quad8": (capi.QUAD8_G3, "grid_quad8", "Quad8 Gauss3*Gauss3"),
@@ -133,19 +139,24 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3")
-    ap.add_argument("--n", type=int, default=0, help="elements per side (default: the BASELINE size)")
+    ap.add_argument("--n", type=int, default=0, help="elements per side (default: the BASELINE size of the workload: cfg2 1000^2, "
+                                                     "cfg3 4000^2, cfg4 200^3, cfg5 125x125x128)")
+    ap.add_argument("--dims", default="", help="3-D workloads: elements per direction as nx,ny,nz (overrides --n)")
     ap.add_argument("--mode", default="overwrite", choices=["overwrite", "accumulate"])
     ap.add_argument("--pattern", default="full", choices=["full", "written"])
     ap.add_argument("--material", default="amor", choices=["amor", "miehe", "bourdin"])
     ap.add_argument("--keep-off-diags", action="store_true")
     ap.add_argument("--force-only", action="store_true", help="GET_INT_VECTOR pass instead of GET_MATRIX0")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: one full-size block per GPU | the one mesh divided")
+    ap.add_argument("--k-halo", default="additive", choices=["additive", "reduce"],
+                    help="N > 1: leave the subdomain matrices additive (Jive's distributed representation) | send the interface rows of K to the lower rank")
     ap.add_argument("--cpu-elems", type=int, default=6250000, help="elements in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from falcon_amd import capi, meshgen
-    from falcon_amd.distributed import StripPartition, halo_sum
+    from falcon_amd.distributed import InterfacePlanK, SlabPartition, halo_sum, halo_sum_K
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -160,30 +171,42 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    wl = workload(args.workload, args.n, capi, args.material, args.keep_off_diags)
+    dims = tuple(int(x) for x in args.dims.split(",")) if args.dims else None
+    wl = workload(args.workload, args.n, capi, args.material, args.keep_off_diags, dims)
     rk = len(wl["dims"])
     t_setup = time.perf_counter()
     part = None
-    if rk == 2:
+    ndofpn = rk + (1 if wl["model"] else 0)
+    if world > 1:
+        if wl["shape"] not in (capi.QUAD4_G2, capi.HEX8_G2):
+            raise SystemExit("multi-GPU bench: block partitions exist for the structured Quad4 and Hex8 meshes")
+        gdims = tuple(wl["dims"])
+        if args.scaling == "weak":      # every rank gets a full-size block, stacked along the last axis
+            gdims = gdims[:-1] + (gdims[-1] * world,)
+        part = SlabPartition(gdims, world, rank, ndofpn)
+        coords, conn = part.local_mesh(meshgen, wl["h"])
+    elif rk == 2:
         nx, ny = wl["dims"]
-        if world > 1:      # weak scaling: every rank gets a full-size strip, stacked in y
-            if wl.get("gen"):
-                raise SystemExit("multi-GPU bench is implemented for the Quad4 strip partition")
-            part = StripPartition(nx, ny * world, world, rank, 3 if wl["model"] else 2)
-            coords, conn = part.local_mesh(meshgen, wl["h"])
-        else:
-            coords, conn = getattr(meshgen, wl.get("gen", "grid_quad4"))(nx, ny, nx * wl["h"], ny * wl["h"])
+        coords, conn = getattr(meshgen, wl.get("gen", "grid_quad4"))(nx, ny, nx * wl["h"], ny * wl["h"])
     else:
         nx, ny, nz = wl["dims"]
         gen = meshgen.grid_hex20 if wl["shape"] in (capi.HEX20_G3, capi.HEX20_G2) else meshgen.grid_hex8
         coords, conn = gen(nx, ny, nz, nx * wl["h"], ny * wl["h"], nz * wl["h"])
-        if world > 1:
-            raise SystemExit("multi-GPU bench is implemented for the 2D strip partition")
     kind = capi.PATTERN_FULL if args.pattern == "full" else capi.PATTERN_WRITTEN
     asm = capi.Assembler(wl["shape"], wl["model"], wl["material"], coords, conn, pattern_kind=kind,
                          device=local_rank, **wl["kw"])
-    state = torch.from_numpy(meshgen.smooth_state(coords, asm.ndofpn, seed=12345 + rank)).to(dev)
+    # N > 1: the state is a function of the coordinates only (no per-rank noise), so interface nodes carry the same
+    # values on both ranks that hold them
+    state = torch.from_numpy(meshgen.smooth_state(coords, asm.ndofpn, seed=12345) if world == 1 else
+                             meshgen.smooth_state(coords, asm.ndofpn, noise=0.0, phi_noise=0.0)).to(dev)
     del coords
+    plan = None
+    if part is not None and args.k_halo == "reduce" and not args.force_only:
+        mask = None
+        if kind == capi.PATTERN_WRITTEN and wl["model"]:
+            keep = bool(wl["kw"].get("keep_off_diags"))
+            mask = np.ones((ndofpn, ndofpn), bool); mask[:rk, rk] = keep; mask[rk, :rk] = keep
+        plan = InterfacePlanK(part, *asm.pattern(), mask=mask)
     want_K = not args.force_only
     K = torch.zeros(asm.nnz, dtype=torch.float64, device=dev) if want_K else None
     f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
@@ -195,6 +218,8 @@ def main():
         asm.assemble(state, K, f, flags=flags)
         if part is not None:
             halo_sum(f, part)
+            if plan is not None:
+                halo_sum_K(K, part, plan)
 
     def barrier():
         if world > 1:
@@ -212,6 +237,8 @@ def main():
         ev[i][1].record()
         if part is not None:
             halo_sum(f, part)
+            if plan is not None:
+                halo_sum_K(K, part, plan)
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -242,11 +269,13 @@ def main():
             "metric": "assembled elements/sec (K + f_int)" if want_K else "assembled elements/sec (f_int only)",
             "value": nel_total * args.steps / elapsed, "unit": "elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["desc"], "elements_per_gpu": asm.nel, "ndof_per_gpu": asm.ndof,
                        "nnz_per_gpu": asm.nnz, "mode": args.mode, "pattern": args.pattern,
-                       "partition": "y-strips, f_int interface halo-sum over RCCL" if world > 1 else "single GPU",
+                       "partition": (f"{world} blocks of element layers along the last axis ({args.scaling} scaling), f_int interface "
+                                     f"halo-sum over RCCL, K {'interface rows reduced to the lower rank' if plan is not None else 'additive'}")
+                                    if world > 1 else "single GPU",
                        "setup_seconds": round(t_setup, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "kernel_ms": kern_ms,

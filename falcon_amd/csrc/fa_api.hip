@@ -862,7 +862,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     if (shape_ok && wanted && canonical_dofs && c->ndof == nnode * nd && nel > 0 && maxval <= 8) {
       const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE;
       const int nodw = fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0);
-      c->fvec.block = (dbg.fvec_blk == 192 || dbg.fvec_blk == 256 || dbg.fvec_blk == 320) ? dbg.fvec_blk : 192;
+      c->fvec.block = (dbg.fvec_blk == 128 || dbg.fvec_blk == 192 || dbg.fvec_blk == 256 || dbg.fvec_blk == 320) ? dbg.fvec_blk : 192;
       fa::TileOpts o;
       o.no_tab = true; o.no_f_image = true; o.fvec = maxval; o.own_doubles = maxval * nd; o.max_el = c->fvec.block;
       o.conn_pad4 = true; o.max_all = 2 * c->fvec.block;
@@ -873,7 +873,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
         c->fvec.conn_stride = tsV.conn_stride;
         // persistent LDS-DMA form: PhaseFracture / MicroPhaseFracture / LinearElasticity, workgroups of 192 or 256
         const bool model_ok = p->model == FA_LINEAR_ELASTICITY || p->model == FA_PHASE_FRACTURE || p->model == FA_MICRO_PHASE_FRACTURE;
-        if (model_ok && (dbg.persist != 0) && (c->fvec.block == 192 || c->fvec.block == 256)) {
+        if (model_ok && (dbg.persist > 0) && (c->fvec.block == 192 || c->fvec.block == 256)) {
           c->fvec.maxn = (tsV.max_all + 63) / 64 * 64; c->fvec.maxe = (tsV.max_el + 63) / 64 * 64;
           const bool hist = p->model != FA_LINEAR_ELASTICITY;
           c->fvec.plds = 2 * fa::stage_bytes_host(pf, sh.nip, c->fvec.maxn, c->fvec.maxe, hist) + tsV.max_own * maxval * nd * 8;

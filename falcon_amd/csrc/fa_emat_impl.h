@@ -494,8 +494,11 @@ __global__ __launch_bounds__(BLK) FA_EMAT_ATTR void assemble_emat(const Params P
 // the node's buffer in that order -- the element order of the reference's serial loop -- and writes f_int.  No
 // atomics, no metadata read after the staging phase, tiles of a few hundred elements (LDS: 5-7 doubles per node and
 // valence x dofs doubles per owned node).
+#ifndef FA_FVEC_ATTR
+#define FA_FVEC_ATTR
+#endif
 template <class SH, int FAM, class SP, int BLK>
-__global__ __launch_bounds__(BLK) void assemble_fvec(const Params P) {
+__global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP;
   constexpr bool PF = (FAM != FAM_LE);
   constexpr int NDOF = PF ? RANK + 1 : RANK;
@@ -861,6 +864,7 @@ static int launch_fvec_one(const Params& P, int grid, hipStream_t st) {
   if (P.tile_block == 320) return go(assemble_fvec<SH, FAM, SP, 320>, 320);
   if (P.tile_block == 192) return go(assemble_fvec<SH, FAM, SP, 192>, 192);
   if (P.tile_block == 256) return go(assemble_fvec<SH, FAM, SP, 256>, 256);
+  if (P.tile_block == 128) return go(assemble_fvec<SH, FAM, SP, 128>, 128);
   return -1000;
 }
 

@@ -981,6 +981,14 @@ __device__ __forceinline__ void stream_out16(double* __restrict__ g, const doubl
     for (; p + BLK < npair; p += 2 * BLK) { const double2 a0 = s2[p], a1 = s2[p + BLK]; g2[p] = a0; g2[p + BLK] = a1; }
     for (; p < npair; p += BLK) g2[p] = s2[p];
   } else {
+    // accumulate: four reads of K in flight per lane before the first add (one at a time, every 32 bytes cost a full
+    // memory round trip: 7.1 -> ms on cfg3)
+    for (; p + 3 * BLK < npair; p += 4 * BLK) {
+      double2 b0 = g2[p], b1 = g2[p + BLK], b2 = g2[p + 2 * BLK], b3 = g2[p + 3 * BLK];
+      const double2 a0 = s2[p], a1 = s2[p + BLK], a2 = s2[p + 2 * BLK], a3 = s2[p + 3 * BLK];
+      b0.x += a0.x; b0.y += a0.y; b1.x += a1.x; b1.y += a1.y; b2.x += a2.x; b2.y += a2.y; b3.x += a3.x; b3.y += a3.y;
+      g2[p] = b0; g2[p + BLK] = b1; g2[p + 2 * BLK] = b2; g2[p + 3 * BLK] = b3;
+    }
     for (; p < npair; p += BLK) { double2 b = g2[p]; const double2 a = s2[p]; b.x += a.x; b.y += a.y; g2[p] = b; }
   }
   const int last = i0 + 2 * npair;

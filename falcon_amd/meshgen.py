@@ -101,7 +101,7 @@ def shuffle_nodes(coords, conn, seed=12345):
     return coords[perm], inv[conn].astype(np.int32), perm
 
 
-def smooth_state(coords, ndofpn, seed=12345, amp=1e-3, noise=1e-6, notch=True, l0=0.015):
+def smooth_state(coords, ndofpn, seed=12345, amp=1e-3, noise=1e-6, notch=True, l0=0.015, phi_noise=0.05):
     """u = amp*(sin pi x cos pi y, cos pi x sin pi y[, sin pi z]) + noise; phi = notch profile.
     Interleaved node-major (dof = node*ndofpn + type), SURVEY.md 8d."""
     rng = np.random.default_rng(seed)
@@ -116,6 +116,6 @@ def smooth_state(coords, ndofpn, seed=12345, amp=1e-3, noise=1e-6, notch=True, l
     if ndofpn > rank:
         mid = coords[:, rank - 1]
         phi = np.exp(-np.abs(mid - 0.5) / l0) * (x < 0.5) if notch else np.zeros(n)
-        phi = phi + 0.05 * rng.uniform(0.0, 1.0, n)
+        phi = phi + phi_noise * rng.uniform(0.0, 1.0, n)      # noise = phi_noise = 0: a function of the coordinates only
         s[:, rank] = np.clip(phi, 0.0, 0.98)
     return s.ravel()
