@@ -5,7 +5,7 @@ for d in sys.argv[1:]:
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(fn)):
             k = r["Kernel_Name"]
-            if "assemble" not in k:
+            if "assemble" not in k and "_kernel" not in k:
                 continue
             acc[(k[:70], r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in sorted(acc.items()):
