@@ -52,7 +52,9 @@ class AssembleArgs(C.Structure):
 EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_nip_total", "fa_ndof_per_node",
            "fa_strain_rows", "fa_uses_row_kernel", "fa_psi0", "fa_patch_stats", "fa_pattern_host", "fa_pattern_device",
            "fa_assemble", "fa_assemble_noalloc", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
-           "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum", "fa_strain_table", "fa_stress_table"]
+           "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum", "fa_strain_table", "fa_stress_table",
+           "fa_pattern_device32", "fa_device", "fa_cons_create", "fa_cons_destroy", "fa_cons_set_rvalues", "fa_cons_eliminate",
+           "fa_cons_eval_masters", "fa_cons_eval_slaves", "fa_residual"]
 
 _lib = None
 
@@ -86,6 +88,15 @@ def lib():
         L.fa_gather_sum.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
         L.fa_strain_table.argtypes = [vp, vp, vp, vp]
         L.fa_stress_table.argtypes = [vp, vp, vp, vp]
+        L.fa_pattern_device32.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+        L.fa_device.argtypes = [vp]; L.fa_device.restype = C.c_int32
+        L.fa_cons_create.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.POINTER(vp)]
+        L.fa_cons_destroy.argtypes = [vp]; L.fa_cons_destroy.restype = None
+        L.fa_cons_set_rvalues.argtypes = [vp, vp, vp]
+        L.fa_cons_eliminate.argtypes = [vp, vp, vp, vp]
+        L.fa_cons_eval_masters.argtypes = [vp, vp, vp]
+        L.fa_cons_eval_slaves.argtypes = [vp, vp, vp]
+        L.fa_residual.argtypes = [vp] * 11
         ip = C.POINTER(C.c_int32)
         L.fa_shape_info.argtypes = [C.c_int32, ip, ip, ip]
         L.fa_shape_tables.argtypes = [C.c_int32, vp, vp, vp]
@@ -165,6 +176,15 @@ class Assembler:
         _check(lib().fa_pattern_host(self.h, _np_ptr(rp), _np_ptr(ci)))
         return rp, ci
 
+    def pattern_device32(self):
+        """(row_ptr, col_idx) device addresses of the pattern with 32-bit offsets (cuDSSSolver.cpp:655-663)."""
+        rp, ci = C.c_void_p(), C.c_void_p()
+        _check(lib().fa_pattern_device32(self.h, C.byref(rp), C.byref(ci)))
+        return rp.value, ci.value
+
+    def constraints(self, slave_dofs, rvalues=None, master_ptr=None, master_dofs=None, master_coefs=None):
+        return Constraints(self, slave_dofs, rvalues, master_ptr, master_dofs, master_coefs)
+
     # ---- device path (torch tensors on cuda:device, float64) ----
     def assemble(self, state, K=None, f=None, *, state0=None, state00=None, dt=0.0, dt0=0.0, err_ext=None,
                  flags=ACCUMULATE, stream=None, noalloc=False):
@@ -241,4 +261,71 @@ class Assembler:
     def get_strain_cache(self):
         out = np.empty((self.nip_total, self.strain_rows))
         _check(lib().fa_get_strain_cache(self.h, _np_ptr(out)))
+        return out
+
+
+class Constraints:
+    """A constraint set on an Assembler's pattern (jive::util::Constraints as the solver wrappers' StdConstrainer and
+    BFGSModule::updateResidual use it): u[slave] = rvalue + sum coef * u[master]."""
+
+    def __init__(self, asm, slave_dofs, rvalues=None, master_ptr=None, master_dofs=None, master_coefs=None):
+        self.asm = asm
+        sd = np.ascontiguousarray(slave_dofs, dtype=np.int64)
+        rv = None if rvalues is None else np.ascontiguousarray(rvalues, dtype=np.float64)
+        mp = None if master_ptr is None else np.ascontiguousarray(master_ptr, dtype=np.int64)
+        md = None if master_dofs is None else np.ascontiguousarray(master_dofs, dtype=np.int64)
+        mc = None if master_coefs is None else np.ascontiguousarray(master_coefs, dtype=np.float64)
+        assert rv is None or rv.size == sd.size
+        assert mp is None or mp.size == sd.size + 1
+        self.nslave = sd.size
+        self.h = C.c_void_p()
+        _check(lib().fa_cons_create(asm.h, sd.size, _np_ptr(sd), _np_ptr(rv), _np_ptr(mp), _np_ptr(md), _np_ptr(mc),
+                                    C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            lib().fa_cons_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except TypeError:
+            pass
+
+    def _stream(self, stream):
+        import torch
+        return torch.cuda.current_stream(self.asm.device).cuda_stream if stream is None else stream
+
+    def _ptr(self, t, n):
+        import torch
+        if t is None:
+            return None
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() >= n, "bad device vector"
+        return t.data_ptr()
+
+    def set_rvalues(self, rvalues, stream=None):
+        rv = np.ascontiguousarray(rvalues, dtype=np.float64)
+        assert rv.size == self.nslave
+        _check(lib().fa_cons_set_rvalues(self.h, _np_ptr(rv), self._stream(stream)))
+
+    def eliminate(self, K, rhs=None, stream=None):
+        """K := T^t K T + I_S, rhs := T^t (rhs - K c), in place (StdConstrainer, cuDSSSolver.cpp:108-121,293)."""
+        _check(lib().fa_cons_eliminate(self.h, self._ptr(K, self.asm.nnz), self._ptr(rhs, self.asm.ndof), self._stream(stream)))
+
+    def eval_masters(self, vec, stream=None):
+        _check(lib().fa_cons_eval_masters(self.h, self._ptr(vec, self.asm.ndof), self._stream(stream)))
+
+    def eval_slaves(self, vec, stream=None):
+        _check(lib().fa_cons_eval_slaves(self.h, self._ptr(vec, self.asm.ndof), self._stream(stream)))
+
+    def residual(self, fext, fint, du, r, *, u=None, lower=None, upper=None, r2=None, out=None, stream=None):
+        """BFGSModule::Work_::updateResidual (BFGSModule.cpp:438-489); returns the device tensor {rnorm, enorm, rnorm^2}."""
+        import torch
+        n = self.asm.ndof
+        if out is None:
+            out = torch.empty(3, dtype=torch.float64, device=r.device)
+        _check(lib().fa_residual(self.h, self._ptr(fext, n), self._ptr(fint, n), self._ptr(du, n), self._ptr(u, n),
+                                 self._ptr(lower, n), self._ptr(upper, n), self._ptr(r, n), self._ptr(r2, n),
+                                 self._ptr(out, 3), self._stream(stream)))
         return out

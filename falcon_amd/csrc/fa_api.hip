@@ -33,6 +33,18 @@ fa_status fail(fa_status code, const char* fmt, ...) {
   return code;
 }
 
+}  // namespace
+
+// error text of the calling thread, for the other translation units of the library
+int fa::set_error(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+namespace {
+
 #define HIP_TRY(expr)                                                                              \
   do { hipError_t _e = (expr);                                                                     \
        if (_e != hipSuccess) return fail(FA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } while (0)
@@ -353,6 +365,7 @@ struct fa_ctx {
           *d_prec = nullptr, *d_prun = nullptr;
   double* d_hist[2] = { nullptr, nullptr };   // [0] preHist_, [1] newHist_
   double* d_strain = nullptr; double* d_err_part = nullptr;
+  int32_t* d_row_ptr32 = nullptr;      // fa_pattern_device32: the offsets as 32-bit integers, made on first request
   // staging for fa_assemble_host
   double *s_state = nullptr, *s_state0 = nullptr, *s_state00 = nullptr, *s_K = nullptr, *s_f = nullptr, *s_err = nullptr;
   std::vector<double> h_tmp;
@@ -368,7 +381,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
   if (!c) return;
   DeviceGuard guard(c->prob.device);
   void* ptrs[] = { c->d_conn, c->d_coords, c->d_row_ptr, c->d_col_idx, c->d_node_dofs, c->d_n2e_ptr, c->d_n2e_ent,
-                   c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part,
+                   c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part, c->d_row_ptr32,
                    c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err,
                    c->d_pn_ptr, c->d_pe_ptr, c->d_pr_ptr, c->d_pnode, c->d_poff, c->d_prec, c->d_prun,
                    c->d_tinfo, c->d_tnodes, c->d_telems, c->d_tconn, c->d_tpairs, c->d_tents,
@@ -1022,6 +1035,31 @@ extern "C" fa_status fa_pattern_device(const fa_ctx* c, const int64_t** row_ptr,
   if (col_idx) *col_idx = c->d_col_idx;
   return FA_OK;
 }
+
+__global__ void narrow_offsets_kernel(int64_t n, const int64_t* __restrict__ in, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int32_t)in[i];
+}
+
+extern "C" fa_status fa_pattern_device32(fa_ctx* c, const int32_t** row_ptr, const int32_t** col_idx) {
+  if (!c) return fail(FA_ERR_ARG, "null argument");
+  if (c->nnz > 2147483647LL)
+    return fail(FA_ERR_UNSUPPORTED, "fa_pattern_device32: %lld stored entries do not fit 32-bit offsets (cuDSSSolver.cpp:655 has the same limit on the matrix size)", (long long)c->nnz);
+  FA_ON_DEVICE(c->prob.device);
+  if (row_ptr) {
+    if (!c->d_row_ptr32) {
+      HIP_TRY(hipMalloc((void**)&c->d_row_ptr32, sizeof(int32_t) * (c->ndof + 1)));
+      hipLaunchKernelGGL(narrow_offsets_kernel, dim3((unsigned)((c->ndof + 256) / 256)), dim3(256), 0, nullptr, c->ndof + 1, c->d_row_ptr, c->d_row_ptr32);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(nullptr));
+    }
+    *row_ptr = c->d_row_ptr32;
+  }
+  if (col_idx) *col_idx = c->d_col_idx;
+  return FA_OK;
+}
+
+extern "C" int32_t fa_device(const fa_ctx* c) { return c ? c->prob.device : -1; }
 
 // noalloc: the call must not allocate -- the strain cache has to exist already and the errExt_ partials go to the
 // file-scope scratch array (through its resolved device address) instead of the context's buffer

@@ -5,6 +5,10 @@
 
 namespace fa {
 
+// sets the calling thread's fa_last_error() text and returns `code` (defined in fa_api.hip)
+int set_error(int code, const char* fmt, ...);
+
+
 // Workgroup geometry per space dimension: threads per workgroup and capacity (in doubles) of the LDS image
 // of the CSR rows.  2D: 128 threads + 20 KiB => 7-8 workgroups per CU; 3D row blocks are ~5x larger.
 #ifndef FA_BLOCK2D

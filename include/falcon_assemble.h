@@ -190,6 +190,55 @@ fa_status fa_stress_table(fa_ctx* ctx, double* table, double* weights, void* str
  * caller divides by the node count and does the allsum over ranks as LodiModel does (:266,:288-289). */
 fa_status fa_gather_sum(fa_ctx* ctx, const double* vec, const int64_t* idx, int64_t n, double* out, void* stream);
 
+/* ---- hand-off of the device-resident K to a linear solver ---- */
+
+/* The pattern with 32-bit offsets: the types the solver wrappers hand to their libraries
+ * (cuDSSSolver.cpp:655-663: JEM_PRECHECK(msize <= maxOf<int>()), offsets_ = castTo<int>(getRowOffsets()),
+ * indices_ = castTo<int>(getColumnIndices()); :692-694 CUDA_R_32I).  The 32-bit offsets are made on the first call and
+ * kept by the context; FA_ERR_UNSUPPORTED when nnz does not fit.  Device pointers. */
+fa_status fa_pattern_device32(fa_ctx* ctx, const int32_t** row_ptr, const int32_t** col_idx);
+/* HIP device ordinal of the context (fa_problem.device) */
+int32_t   fa_device(const fa_ctx* ctx);
+
+/* Constraints in the form jive::util::Constraints holds them (the reference creates them in DirichletModel.cpp:287,
+ * DispArclenBCs.cpp:358,440,494, PeriodicModel.cpp:287, GradientDamageModel.cpp:843, StaggeredModule.cpp:767-1031):
+ *     u[slave_dofs[k]] = rvalues[k] + sum_{q = master_ptr[k]}^{master_ptr[k+1]-1} master_coefs[q] * u[master_dofs[q]]
+ * HOST arrays; rvalues NULL => 0; master_ptr NULL => no masters (plain Dirichlet conditions).  A master must not be a
+ * slave (the compressed form, Constraints::compress).  The pattern of the context must hold every entry the
+ * elimination writes -- (j, master) for every stored (j, slave), (master, q) for every stored (slave, q), the slaves'
+ * diagonal -- otherwise FA_ERR_ARG names the missing entry; plain Dirichlet conditions never need extra entries.
+ * The constraint set is tied to the context's pattern and device; destroy it before the context. */
+typedef struct fa_cons fa_cons;
+fa_status fa_cons_create(fa_ctx* ctx, int64_t nslave, const int64_t* slave_dofs, const double* rvalues,
+                         const int64_t* master_ptr, const int64_t* master_dofs, const double* master_coefs,
+                         fa_cons** out);
+void      fa_cons_destroy(fa_cons* cons);
+/* new right-hand values (they change with every load step, DispArclenBCs.cpp:494); host array of nslave doubles */
+fa_status fa_cons_set_rvalues(fa_cons* cons, const double* rvalues, void* stream);
+
+/* What StdConstrainer does to the system before the solver library sees it (cuDSSSolver.cpp:108-121: matrix_ =
+ * conman_->getOutputMatrix(); :293 conman_->getRhs(f, rhs)), in place on the device arrays:
+ *     K   := T^t K T + I_S        (slave rows / columns folded into the masters, then zeroed; unit diagonal)
+ *     rhs := T^t (rhs - K c)      (c = rvalues on the slaves; rhs[slaves] = 0)
+ * with u = T u + c the constraints.  K_values: nnz doubles as fa_assemble wrote them; rhs: ndof doubles or NULL.
+ * Only the entries in slave rows / columns and their fold destinations are touched: O(boundary) per call.  No atomics;
+ * bitwise repeatable.  After the solve, fa_cons_eval_slaves gives the slave entries of the solution (:416 getLhs). */
+fa_status fa_cons_eliminate(const fa_cons* cons, double* K_values, double* rhs, void* stream);
+/* jive::util::evalMasterDofs (BFGSModule.cpp:443, LodiModel.cpp:265, TSArclenModule.cpp:520,641): vec[master] +=
+ * coef * vec[slave], vec[slave] = 0.  Device vector of ndof doubles. */
+fa_status fa_cons_eval_masters(const fa_cons* cons, double* vec, void* stream);
+/* jive::util::evalSlaveDofs: vec[slave] = rvalue + sum coef * vec[master]. */
+fa_status fa_cons_eval_slaves(const fa_cons* cons, double* vec, void* stream);
+
+/* BFGSModule::Work_::updateResidual (BFGSModule.cpp:438-489) on device vectors of ndof doubles:
+ *     r = fext - fint;  evalMasterDofs(r);
+ *     unbounded (lower == upper == NULL): rnorm = norm2(r), enorm = r . du
+ *     bounded: r2[i] = -r[i] clipped by the active bounds of u (:452-479), rnorm = norm2(r2), enorm = r2 . du
+ * out (device, 3 doubles) = { rnorm, enorm, rnorm^2 }: rnorm is not yet divided by rscale (:485-488); rnorm^2 is what a
+ * multi-rank caller sums over ranks.  cons may hold zero slaves.  Fixed-order two-stage sums: bitwise repeatable. */
+fa_status fa_residual(const fa_cons* cons, const double* fext, const double* fint, const double* du, const double* u,
+                      const double* lower, const double* upper, double* r, double* r2, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,6 +130,19 @@ int  fo_assemble(const fo_config* cfg,
                  double* strain_cache,
                  double* K_values, double* f_int, double* err_ext);
 
+/* ---- constraints and residual (falcon_oracle_cons.c) ----
+ * u[slave[k]] = rval[k] + sum_{q in mptr[k]..mptr[k+1]} mcoef[q] * u[mdof[q]]; rval / mptr may be NULL */
+typedef struct {
+  int64_t nslave; const int64_t* slave; const double* rval;
+  const int64_t* mptr; const int64_t* mdof; const double* mcoef;
+} fo_cons;
+void fo_eval_masters(double* vec, const fo_cons* c);
+void fo_eval_slaves(double* vec, const fo_cons* c);
+int  fo_cons_eliminate(int64_t ndof, const int64_t* row_ptr, const int32_t* col_idx, double* K, double* rhs,
+                       const fo_cons* c);
+void fo_residual(int64_t n, const fo_cons* c, const double* fext, const double* fint, const double* du,
+                 const double* u, const double* lower, const double* upper, double* r, double* r2, double* out);
+
 const char* fo_last_error(void);
 
 #ifdef __cplusplus

@@ -38,6 +38,11 @@ class ShapeInfo(C.Structure):
     _fields_ = [("rank", C.c_int), ("npe", C.c_int), ("nip", C.c_int), ("str", C.c_int)]
 
 
+class Cons(C.Structure):
+    _fields_ = [("nslave", C.c_int64), ("slave", C.POINTER(C.c_int64)), ("rval", C.POINTER(C.c_double)),
+                ("mptr", C.POINTER(C.c_int64)), ("mdof", C.POINTER(C.c_int64)), ("mcoef", C.POINTER(C.c_double))]
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
@@ -68,6 +73,11 @@ def lib():
         L.fo_strain_table.argtypes = [C.c_int, C.c_int64, ip32, dp, C.c_int, C.c_int, dp, dp]
         L.fo_stress_table.argtypes = [C.POINTER(Config), C.c_int64, ip32, dp, C.c_int, dp, dp]
         L.fo_last_error.restype = C.c_char_p
+        L.fo_eval_masters.argtypes = [dp, C.POINTER(Cons)]; L.fo_eval_masters.restype = None
+        L.fo_eval_slaves.argtypes = [dp, C.POINTER(Cons)]; L.fo_eval_slaves.restype = None
+        L.fo_cons_eliminate.argtypes = [C.c_int64, ip64, ip32, dp, dp, C.POINTER(Cons)]
+        L.fo_residual.argtypes = [C.c_int64, C.POINTER(Cons), dp, dp, dp, dp, dp, dp, dp, dp, dp]
+        L.fo_residual.restype = None
         _lib = L
     return _lib
 
@@ -211,3 +221,45 @@ def assemble(cfg, coords, conn, row_ptr, col_idx, state, state0=None, state00=No
         raise ValueError(lib().fo_last_error().decode())
     return dict(K=K if want_K else None, f=f, hist_new=hist_new, strain=strain, err_ext=err.value,
                 micro_stale_hits=int(lib().fo_micro_stale_hits()))
+
+
+class Constraints:
+    """u[slave] = rval + sum coef * u[master] (falcon_oracle_cons.c)."""
+
+    def __init__(self, slave, rval=None, mptr=None, mdof=None, mcoef=None):
+        self.slave = np.ascontiguousarray(slave, dtype=np.int64)
+        self.rval = None if rval is None else np.ascontiguousarray(rval, dtype=np.float64)
+        self.mptr = None if mptr is None else np.ascontiguousarray(mptr, dtype=np.int64)
+        self.mdof = None if mdof is None else np.ascontiguousarray(mdof, dtype=np.int64)
+        self.mcoef = None if mcoef is None else np.ascontiguousarray(mcoef, dtype=np.float64)
+        self.c = Cons(self.slave.size, _p(self.slave, C.c_int64), _p(self.rval, C.c_double), _p(self.mptr, C.c_int64),
+                      _p(self.mdof, C.c_int64), _p(self.mcoef, C.c_double))
+
+    def eval_masters(self, vec):
+        assert vec.dtype == np.float64 and vec.flags.c_contiguous
+        lib().fo_eval_masters(_p(vec, C.c_double), C.byref(self.c))
+        return vec
+
+    def eval_slaves(self, vec):
+        assert vec.dtype == np.float64 and vec.flags.c_contiguous
+        lib().fo_eval_slaves(_p(vec, C.c_double), C.byref(self.c))
+        return vec
+
+    def eliminate(self, row_ptr, col_idx, K, rhs=None):
+        """in place; raises when the pattern lacks a fill-in entry"""
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64); col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+        assert K.dtype == np.float64 and K.flags.c_contiguous
+        rc = lib().fo_cons_eliminate(row_ptr.size - 1, _p(row_ptr, C.c_int64), _p(col_idx, C.c_int32), _p(K, C.c_double),
+                                     _p(rhs, C.c_double), C.byref(self.c))
+        if rc:
+            raise ValueError("the pattern lacks an entry the elimination writes")
+        return K, rhs
+
+    def residual(self, fext, fint, du, u=None, lower=None, upper=None):
+        """(r, r2 or None, [rnorm, enorm, rnorm^2]) of BFGSModule::Work_::updateResidual"""
+        n = fext.size
+        r = np.zeros(n); r2 = np.zeros(n) if lower is not None else None; out = np.zeros(3)
+        a = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in (fext, fint, du, u, lower, upper)]
+        lib().fo_residual(n, C.byref(self.c), *[_p(v, C.c_double) for v in a], _p(r, C.c_double), _p(r2, C.c_double),
+                          _p(out, C.c_double))
+        return r, r2, out
