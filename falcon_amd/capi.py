@@ -54,7 +54,7 @@ EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_
            "fa_assemble", "fa_assemble_noalloc", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
            "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum", "fa_strain_table", "fa_stress_table",
            "fa_pattern_device32", "fa_device", "fa_cons_create", "fa_cons_destroy", "fa_cons_set_rvalues", "fa_cons_eliminate",
-           "fa_cons_eval_masters", "fa_cons_eval_slaves", "fa_residual"]
+           "fa_cons_eval_masters", "fa_cons_eval_slaves", "fa_residual", "fa_arc_func"]
 
 _lib = None
 
@@ -97,6 +97,7 @@ def lib():
         L.fa_cons_eval_masters.argtypes = [vp, vp, vp]
         L.fa_cons_eval_slaves.argtypes = [vp, vp, vp]
         L.fa_residual.argtypes = [vp] * 11
+        L.fa_arc_func.argtypes = [vp] * 6
         ip = C.POINTER(C.c_int32)
         L.fa_shape_info.argtypes = [C.c_int32, ip, ip, ip]
         L.fa_shape_tables.argtypes = [C.c_int32, vp, vp, vp]
@@ -233,6 +234,18 @@ class Assembler:
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         _check(lib().fa_stress_table(self.h, table.data_ptr(), weights.data_ptr(), stream))
+
+    def arc_func(self, state, state0, jac10, fe_dissipation=None, stream=None):
+        """getArcFunc_ (PhaseFractureModel.cpp:844-1063): fills jac10, returns the device scalar FE_DISSIPATION."""
+        import torch
+        for t in (state, state0, jac10):
+            assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() >= self.ndof
+        if fe_dissipation is None:
+            fe_dissipation = torch.empty(1, dtype=torch.float64, device=state.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().fa_arc_func(self.h, state.data_ptr(), state0.data_ptr(), jac10.data_ptr(), fe_dissipation.data_ptr(), stream))
+        return fe_dissipation
 
     def gather_sum(self, vec, idx, out=None, stream=None):
         """sum of vec[idx] (idx < 0 skipped) on the device: LodiModel's load / disp sums (LodiModel.cpp:263-283)."""

@@ -365,6 +365,7 @@ struct fa_ctx {
           *d_prec = nullptr, *d_prun = nullptr;
   double* d_hist[2] = { nullptr, nullptr };   // [0] preHist_, [1] newHist_
   double* d_strain = nullptr; double* d_err_part = nullptr;
+  double* d_arc_part = nullptr;        // fa_arc_func: per-workgroup partial sums of FE_DISSIPATION
   int32_t* d_row_ptr32 = nullptr;      // fa_pattern_device32: the offsets as 32-bit integers, made on first request
   // staging for fa_assemble_host
   double *s_state = nullptr, *s_state0 = nullptr, *s_state00 = nullptr, *s_K = nullptr, *s_f = nullptr, *s_err = nullptr;
@@ -381,7 +382,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
   if (!c) return;
   DeviceGuard guard(c->prob.device);
   void* ptrs[] = { c->d_conn, c->d_coords, c->d_row_ptr, c->d_col_idx, c->d_node_dofs, c->d_n2e_ptr, c->d_n2e_ent,
-                   c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part, c->d_row_ptr32,
+                   c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part, c->d_row_ptr32, c->d_arc_part,
                    c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err,
                    c->d_pn_ptr, c->d_pe_ptr, c->d_pr_ptr, c->d_pnode, c->d_poff, c->d_prec, c->d_prun,
                    c->d_tinfo, c->d_tnodes, c->d_telems, c->d_tconn, c->d_tpairs, c->d_tents,
@@ -1293,6 +1294,26 @@ extern "C" fa_status fa_stress_table(fa_ctx* c, double* table, double* weights, 
   const int rc = (c->rank == 2) ? fa::launch_stress_table_2d(P, c->npe, c->nip, ps, table, weights, stream)
                                 : fa::launch_stress_table_3d(P, c->npe, c->nip, ps, table, weights, stream);
   if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return FA_OK;
+}
+
+// getArcFunc_ (PhaseFractureModel.cpp:844-1063)
+extern "C" fa_status fa_arc_func(fa_ctx* c, const double* state, const double* state0, double* jac10, double* fe_dissipation,
+                                 void* stream) {
+  if (!c || !state || !state0 || !jac10 || !fe_dissipation) return fail(FA_ERR_ARG, "null argument");
+  if (c->prob.model != FA_PHASE_FRACTURE) return fail(FA_ERR_UNSUPPORTED, "fa_arc_func: getArcFunc_ is provided for PhaseFracture only");
+  FA_ON_DEVICE(c->prob.device);
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)((c->nnode + 127) / 128);
+  if (!c->d_arc_part) HIP_TRY(hipMalloc((void**)&c->d_arc_part, sizeof(double) * std::max(1, nblk)));
+  HIP_TRY(hipMemsetAsync(jac10, 0, sizeof(double) * c->ndof, st));     // jac10 = 0.0 (:870): dofs of other models too
+  fa::Params P = c->P;
+  P.state = state;
+  const int rc = (c->rank == 2) ? fa::launch_arc_func_2d(P, c->npe, c->nip, state0, jac10, c->d_arc_part, stream)
+                                : fa::launch_arc_func_3d(P, c->npe, c->nip, state0, jac10, c->d_arc_part, stream);
+  if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  hipLaunchKernelGGL(reduce_err_kernel, dim3(1), dim3(256), 0, st, c->d_arc_part, nblk, fe_dissipation);
+  HIP_TRY(hipGetLastError());
   return FA_OK;
 }
 

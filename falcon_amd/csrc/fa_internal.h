@@ -182,4 +182,8 @@ int launch_fvec_tri3_g1 (const Params&, int fam, int grid, void* stream);
 int launch_stress_table_2d(const Params&, int npe, int nip, int plane_stress, double* table, double* weights, void* stream);
 int launch_stress_table_3d(const Params&, int npe, int nip, int plane_stress, double* table, double* weights, void* stream);
 
+// getArcFunc_ kernels (same translation units)
+int launch_arc_func_2d(const Params&, int npe, int nip, const double* state0, double* jac10, double* part, void* stream);
+int launch_arc_func_3d(const Params&, int npe, int nip, const double* state0, double* jac10, double* part, void* stream);
+
 }  // namespace fa

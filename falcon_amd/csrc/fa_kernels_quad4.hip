@@ -8,6 +8,10 @@ int launch_quad4_g2(const Params& P, int fam, bool want_K, bool keep, int path, 
   if (path == PATH_TILES) return launch_tiles_shape<Shape<2,4,4>>(P, fam, want_K, keep, grid, stream);
   return launch_shape<Shape<2,4,4>>(P, fam, want_K, keep, path, grid, stream);
 }
+int launch_arc_func_2d(const Params& P, int npe, int nip, const double* state0, double* jac10, double* part, void* stream) {
+  return launch_arc_func_rank<2>(P, npe, nip, state0, jac10, part, stream);
+}
+
 int launch_stress_table_2d(const Params& P, int npe, int nip, int plane_stress, double* table, double* weights, void* stream) {
   return launch_stress_table_rank<2>(P, npe, nip, plane_stress, table, weights, stream);
 }

@@ -566,6 +566,140 @@ static int launch_stress_table_rank(const Params& P, int npe, int nip, int plane
   return (int)hipGetLastError();
 }
 
+// getArcFunc_ (PhaseFractureModel.cpp:844-1063): one lane per node over its incident elements (ascending, like the
+// reference's element loop reaches the node); per Gauss point the strain, the current and old degradation, the material
+// update with the current one (Psi = givePsi(), sigma+ = giveDerivPsi(), no history maximum: :1033-1038), then
+//   jac10[disp dofs of the node] += wip (g0 - g) B_a^t sigma+,   jac10[phi dof] -= wip N_a g' Psi          (:1048-1049)
+// summed per element first.  The lane of an element's local node 0 also adds the element's share of FE_DISSIPATION
+// (:1046); per-workgroup partial sums in part[], reduced afterwards in a fixed order.  No atomics.
+template <int RANK>
+__global__ __launch_bounds__(128) void arc_func_kernel(const Params P, int npe, int nip, const double* __restrict__ state0,
+                                                       double* __restrict__ jac10, double* __restrict__ part) {
+  constexpr int S = (RANK == 2) ? 3 : 6, ND = RANK + 1;
+  __shared__ double sfv[128];
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  auto dof = [&](int64_t node, int t) -> int64_t { return P.node_dofs ? P.node_dofs[node * ND + t] : node * ND + t; };
+  double acc[ND], fv = 0.0;
+#pragma unroll
+  for (int c = 0; c < ND; c++) acc[c] = 0.0;
+  if (n < P.nnode) {
+    const double* tabN = P.tab;
+    const double* tabD = P.tab + (size_t)nip * npe;
+    const double* tabW = tabD + (size_t)nip * npe * RANK;
+    for (int32_t t = P.n2e_ptr[n]; t < P.n2e_ptr[n + 1]; t++) {
+      const int32_t ent = P.n2e_ent[t];
+      const int64_t e = ent / npe; const int la = ent - (int32_t)e * npe;
+      const int32_t* cn = P.conn + e * npe;
+      double el[ND], efv = 0.0;
+#pragma unroll
+      for (int c = 0; c < ND; c++) el[c] = 0.0;
+#pragma unroll 1
+      for (int ip = 0; ip < nip; ip++) {
+        const double* dn = tabD + (size_t)ip * npe * RANK;
+        double J[RANK][RANK], inv[RANK][RANK], det;
+#pragma unroll
+        for (int i = 0; i < RANK; i++)
+#pragma unroll
+          for (int k = 0; k < RANK; k++) J[i][k] = 0.0;
+        for (int b = 0; b < npe; b++) {
+          const double* xb = P.coords + (int64_t)cn[b] * RANK;
+#pragma unroll
+          for (int i = 0; i < RANK; i++)
+#pragma unroll
+            for (int k = 0; k < RANK; k++) J[i][k] += xb[i] * dn[b * RANK + k];
+        }
+        if constexpr (RANK == 2) {
+          det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+          const double rd = 1.0 / det;
+          inv[0][0] = J[1][1] * rd;  inv[0][1] = -J[0][1] * rd;
+          inv[1][0] = -J[1][0] * rd; inv[1][1] = J[0][0] * rd;
+        } else {
+          const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+          const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+          const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+          det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+          const double rd = 1.0 / det;
+          inv[0][0] = c00 * rd;
+          inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
+          inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * rd;
+          inv[1][0] = c01 * rd;
+          inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * rd;
+          inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rd;
+          inv[2][0] = c02 * rd;
+          inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
+          inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
+        }
+        double eps[S], pf = 0.0, pf0 = 0.0, ga[RANK];
+#pragma unroll
+        for (int c = 0; c < S; c++) eps[c] = 0.0;
+        for (int b = 0; b < npe; b++) {
+          double g[RANK], u[RANK];
+#pragma unroll
+          for (int i = 0; i < RANK; i++) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < RANK; k++) sacc += dn[b * RANK + k] * inv[k][i];
+            g[i] = sacc; u[i] = P.state[dof(cn[b], i)];
+          }
+          if (b == la) {
+#pragma unroll
+            for (int i = 0; i < RANK; i++) ga[i] = g[i];
+          }
+          if constexpr (RANK == 2) {
+            eps[0] += g[0] * u[0]; eps[1] += g[1] * u[1];
+            eps[2] += g[1] * u[0]; eps[2] += g[0] * u[1];
+          } else {
+            eps[0] += g[0] * u[0]; eps[1] += g[1] * u[1]; eps[2] += g[2] * u[2];
+            eps[3] += g[1] * u[0]; eps[3] += g[0] * u[1];
+            eps[4] += g[2] * u[1]; eps[4] += g[1] * u[2];
+            eps[5] += g[0] * u[2]; eps[5] += g[2] * u[0];
+          }
+          const double Nb = tabN[ip * npe + b];
+          const int64_t pd = dof(cn[b], RANK);
+          pf += Nb * P.state[pd]; pf0 += Nb * state0[pd];
+        }
+        double gphi, dgphi, ddg, gphi0, t1, t2;
+        degrade<SpecRuntime>(P, pf, gphi, dgphi, ddg);
+        degrade<SpecRuntime>(P, pf0, gphi0, t1, t2);
+        double sig[S], sp[S], Psi;
+        if (P.material == 3) {
+          double D[S][S];
+          miehe_update<RANK, S>(P, eps, gphi, D, sig, sp, Psi);
+        } else {
+          double d0, d1, d3;
+          iso_update<RANK, S, SpecRuntime>(P, eps, gphi, d0, d1, d3, sig, sp, Psi);
+        }
+        const double wip = tabW[ip] * det;
+        double bt[RANK];
+        Bt_vec<RANK, S>(ga, sp, bt);
+#pragma unroll
+        for (int i = 0; i < RANK; i++) el[i] += wip * (gphi0 - gphi) * bt[i];
+        el[RANK] -= wip * tabN[ip * npe + la] * dgphi * Psi;
+        if (la == 0) efv += wip * (gphi0 - gphi) * Psi;
+      }
+#pragma unroll
+      for (int c = 0; c < ND; c++) acc[c] += el[c];
+      fv += efv;
+    }
+#pragma unroll
+    for (int c = 0; c < ND; c++) jac10[dof(n, c)] = acc[c];
+  }
+  sfv[threadIdx.x] = fv;
+  __syncthreads();
+  for (int w = 64; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sfv[threadIdx.x] += sfv[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sfv[0];
+}
+
+template <int RANK>
+static int launch_arc_func_rank(const Params& P, int npe, int nip, const double* state0, double* jac10, double* part, void* stream) {
+  hipLaunchKernelGGL(arc_func_kernel<RANK>, dim3((unsigned)((P.nnode + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
+                     P, npe, nip, state0, jac10, part);
+  return (int)hipGetLastError();
+}
+
 template <class SH>
 static int launch_tiles_shape(const Params& P, int fam, bool want_K, bool keep, int grid, void* stream) {
   hipStream_t st = (hipStream_t)stream;

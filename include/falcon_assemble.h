@@ -182,6 +182,15 @@ fa_status fa_strain_table(fa_ctx* ctx, double* table, double* weights, void* str
  * degradation (`update(stressIp, stiff, strainIp, gphiEx, ipoint)`), all str components (2-D: xx, yy, zz, xy). */
 fa_status fa_stress_table(fa_ctx* ctx, double* table, double* weights, void* stream);
 
+/* getArcFunc_ (PhaseFractureModel.cpp:844-1063; ArclenActions::GET_ARC_FUNC of the dissipation-based
+ * arc-length solver, TSArclenModule.cpp:612-641): the same Gauss-point loop as getMatrix_ with other outputs --
+ *     jac10 (device, ndof doubles; zeroed and filled, :870,:1055-1056) = d(dissipation)/d(state)
+ *     fe_dissipation (device, 1 double) = sum wip (g(phi0) - g(phi)) Psi        (XProps::FE_DISSIPATION, :1046,:1059)
+ * jac11 is 0 (:871).  state / state0: StateVector::get / getOld (:860-861), device.  PhaseFracture only.  One lane per
+ * node over its elements, no atomics; bitwise repeatable. */
+fa_status fa_arc_func(fa_ctx* ctx, const double* state, const double* state0, double* jac10, double* fe_dissipation,
+                      void* stream);
+
 /* Host consumers of f_int / state: LodiModel sums the internal force and the state over the dofs
  * of a node group on every GET_MATRIX0 / GET_INT_VECTOR (src/io/models/LodiModel.cpp:263-283: load[i] +=
  * fint1[idofs(i,j)], disp[i] += state[idofs(i,j)], entries < 0 skipped).  With a device-resident f_int that is one

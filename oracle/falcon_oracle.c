@@ -1233,3 +1233,82 @@ int fo_assemble(const fo_config* cfg,
   if (err_ext) *err_ext = errExt;
   return 0;
 }
+
+/* PhaseFractureModel::getArcFunc_ (PhaseFractureModel.cpp:844-1063): the dissipation-based arc-length function of
+ * the element loop.  jac10[ndof] is zeroed and filled (:870, :1055-1056); *fvalue = FE_DISSIPATION (:1046, :1059);
+ * jac11 is 0 (:871).  Psi / stressP are givePsi() / giveDerivPsi() of the update with the CURRENT degradation (no
+ * history maximum here, :1033-1038). */
+int fo_arc_func(const fo_config* cfg, int nnode, const double* coords, int64_t nel, const int32_t* conn,
+                const double* state, const double* state0, double* jac10, double* fvalue_out) {
+  shape_t sh;
+  if (shape_init(&sh, cfg->shape)) return -1;
+  if (cfg->model != FO_PHASE_FRACTURE) FAIL("getArcFunc_ is restated for PhaseFractureModel only");
+  const int rank = sh.rank, nodeCount = sh.npe, ipCount = sh.nip;
+  const int strCount = STRAIN_COUNTS[rank];
+  const int dispCount = nodeCount * rank, phiCount = nodeCount;
+  const int ndofpn = rank + 1;
+  frac_t fr; memset(&fr, 0, sizeof fr);
+  if (frac_init(cfg, &fr)) return -1;
+  const double p_ = fr.p, a1_ = fr.a1, a2_ = fr.a2, a3_ = fr.a3;
+
+  static __thread double grads[MAXNIP][MAXNPE][3];
+  static __thread double bd[MAXSTR * MAXND];
+  double xc[MAXNPE][3], ipWeights[MAXNIP];
+  double disp[MAXND], phi[MAXNPE], phi0[MAXNPE];
+  double stiff[MAXSTR * MAXSTR], stress[MAXSTR], strain[MAXSTR], stressP[MAXSTR];
+  double elemjac10_1[MAXND], elemjac10_2[MAXNPE];
+  int64_t dispDofs[MAXND], phiDofs[MAXNPE];
+  double fvalue = 0.0;
+
+  for (int64_t i = 0; i < (int64_t)nnode * ndofpn; i++) jac10[i] = 0.0;
+  for (int64_t ie = 0; ie < nel; ie++) {
+    const int32_t* inodes = conn + ie * nodeCount;
+    for (int a = 0; a < nodeCount; a++) {
+      for (int i = 0; i < 3; i++) xc[a][i] = (i < rank) ? coords[(int64_t)inodes[a] * rank + i] : 0.0;
+      for (int i = 0; i < rank; i++) dispDofs[a * rank + i] = (int64_t)inodes[a] * ndofpn + i;
+      phiDofs[a] = (int64_t)inodes[a] * ndofpn + rank;
+    }
+    if (shape_gradients(&sh, (const double (*)[3])xc, grads, ipWeights)) return -1;
+    for (int i = 0; i < dispCount; i++) disp[i] = state[dispDofs[i]];
+    for (int a = 0; a < phiCount; a++) { phi[a] = state[phiDofs[a]]; phi0[a] = state0[phiDofs[a]]; }
+    memset(elemjac10_1, 0, sizeof elemjac10_1); memset(elemjac10_2, 0, sizeof elemjac10_2);
+    for (int ip = 0; ip < ipCount; ip++) {
+      fill_B(rank, nodeCount, (const double (*)[3])grads[ip], bd);
+      for (int c = 0; c < strCount; c++) {
+        double s = 0.0;
+        for (int j = 0; j < dispCount; j++) s += bd[c * dispCount + j] * disp[j];
+        strain[c] = s;
+      }
+      const double* Nip = sh.N[ip];
+      const double pf = dotn(phiCount, Nip, phi), pf0 = dotn(phiCount, Nip, phi0);
+      double gphi, gphi0, dgphi;
+      {
+        const double gphi_n = pow(1 - pf, p_);
+        const double gphi_d = gphi_n + a1_ * pf + a1_ * a2_ * pf * pf + a1_ * a2_ * a3_ * pf * pf * pf;
+        gphi = gphi_n / gphi_d + 1.e-7;
+        const double dgphi_n = -p_ * (pow(1 - pf, p_ - 1));
+        const double dgphi_d = dgphi_n + a1_ + 2.0 * a1_ * a2_ * pf + 3.0 * a1_ * a2_ * a3_ * pf * pf;
+        dgphi = (dgphi_n * gphi_d - gphi_n * dgphi_d) / (gphi_d * gphi_d);
+      }
+      {
+        const double gphi_n = pow(1 - pf0, p_);
+        const double gphi_d = gphi_n + a1_ * pf0 + a1_ * a2_ * pf0 * pf0 + a1_ * a2_ * a3_ * pf0 * pf0 * pf0;
+        gphi0 = gphi_n / gphi_d + 1.e-7;
+      }
+      double Psi;
+      if (fo_material_update(cfg, rank, strain, gphi, stress, stiff, &Psi, stressP)) return -1;
+      const double wip = ipWeights[ip];
+      fvalue += wip * (gphi0 - gphi) * Psi;
+      for (int i = 0; i < dispCount; i++) {              /* elemjac10_1 += wip (gphi0 - gphi) bdt stressP */
+        double s = 0.0;
+        for (int c = 0; c < strCount; c++) s += bd[c * dispCount + i] * stressP[c];
+        elemjac10_1[i] += wip * (gphi0 - gphi) * s;
+      }
+      for (int a = 0; a < phiCount; a++) elemjac10_2[a] -= wip * Nip[a] * dgphi * Psi;
+    }
+    for (int i = 0; i < dispCount; i++) jac10[dispDofs[i]] += elemjac10_1[i];
+    for (int a = 0; a < phiCount; a++) jac10[phiDofs[a]] += elemjac10_2[a];
+  }
+  *fvalue_out = fvalue;
+  return 0;
+}

@@ -143,6 +143,11 @@ int  fo_cons_eliminate(int64_t ndof, const int64_t* row_ptr, const int32_t* col_
 void fo_residual(int64_t n, const fo_cons* c, const double* fext, const double* fint, const double* du,
                  const double* u, const double* lower, const double* upper, double* r, double* r2, double* out);
 
+/* PhaseFractureModel::getArcFunc_ (PhaseFractureModel.cpp:844-1063): jac10[nnode*ndofpn] (zeroed, then filled) and
+ * the dissipation increment FE_DISSIPATION; jac11 = 0.  PhaseFracture only. */
+int fo_arc_func(const fo_config* cfg, int nnode, const double* coords, int64_t nel, const int32_t* conn,
+                const double* state, const double* state0, double* jac10, double* fvalue);
+
 const char* fo_last_error(void);
 
 #ifdef __cplusplus

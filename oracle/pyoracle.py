@@ -73,6 +73,7 @@ def lib():
         L.fo_strain_table.argtypes = [C.c_int, C.c_int64, ip32, dp, C.c_int, C.c_int, dp, dp]
         L.fo_stress_table.argtypes = [C.POINTER(Config), C.c_int64, ip32, dp, C.c_int, dp, dp]
         L.fo_last_error.restype = C.c_char_p
+        L.fo_arc_func.argtypes = [C.POINTER(Config), C.c_int, dp, C.c_int64, ip32, dp, dp, dp, dp]
         L.fo_eval_masters.argtypes = [dp, C.POINTER(Cons)]; L.fo_eval_masters.restype = None
         L.fo_eval_slaves.argtypes = [dp, C.POINTER(Cons)]; L.fo_eval_slaves.restype = None
         L.fo_cons_eliminate.argtypes = [C.c_int64, ip64, ip32, dp, dp, C.POINTER(Cons)]
@@ -221,6 +222,18 @@ def assemble(cfg, coords, conn, row_ptr, col_idx, state, state0=None, state00=No
         raise ValueError(lib().fo_last_error().decode())
     return dict(K=K if want_K else None, f=f, hist_new=hist_new, strain=strain, err_ext=err.value,
                 micro_stale_hits=int(lib().fo_micro_stale_hits()))
+
+
+def arc_func(cfg, coords, conn, state, state0):
+    """getArcFunc_: (jac10[ndof], fe_dissipation)"""
+    coords = np.ascontiguousarray(coords, dtype=np.float64); conn = np.ascontiguousarray(conn, dtype=np.int32)
+    state = np.ascontiguousarray(state, dtype=np.float64); state0 = np.ascontiguousarray(state0, dtype=np.float64)
+    jac10 = np.zeros(state.size); fv = C.c_double(0.0)
+    rc = lib().fo_arc_func(C.byref(cfg), coords.shape[0], _p(coords, C.c_double), conn.shape[0], _p(conn, C.c_int32),
+                           _p(state, C.c_double), _p(state0, C.c_double), _p(jac10, C.c_double), C.byref(fv))
+    if rc:
+        raise ValueError(lib().fo_last_error().decode())
+    return jac10, fv.value
 
 
 class Constraints:

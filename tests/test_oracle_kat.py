@@ -557,3 +557,39 @@ def test_micro_newton_oracle_vs_numpy(frac_type, frac):
             exp[e * 4 + ip] = d
     assert {"load", "keep"} <= branches
     assert np.abs(out["hist_new"] - exp).max() < 1e-12
+
+
+@pytest.mark.parametrize("shape,mesh", [(po.QUAD4_G2, lambda: meshgen.grid_quad4(5, 4, 2.0, 1.5)),
+                                        (po.HEX8_G2, lambda: meshgen.grid_hex8(3, 2, 2, 1.0, 2.0, 1.5))])
+def test_arc_func_closed_form_for_uniform_fields(shape, mesh):
+    """getArcFunc_ (PhaseFractureModel.cpp:844-1063) with a uniform strain and uniform phase fields:
+    FE_DISSIPATION = V (g(phi0) - g(phi)) Psi, sum of the phi rows of jac10 = -V g'(phi) Psi (partition of unity),
+    sum of every displacement component of jac10 = 0 (sum_a B_a = 0)."""
+    c0, conn = mesh()
+    coords = meshgen.distort(c0, conn, 0.1, 3)
+    rank = coords.shape[1]
+    on_boundary = np.zeros(c0.shape[0], bool)
+    for i in range(rank):
+        on_boundary |= (np.abs(c0[:, i] - c0[:, i].min()) < 1e-12) | (np.abs(c0[:, i] - c0[:, i].max()) < 1e-12)
+    coords[on_boundary] = c0[on_boundary]                 # the volume stays that of the box
+    nd = rank + 1
+    cfg = po.make_config(shape, po.PHASE_FRACTURE, po.BOURDIN, young=100.0, poisson=0.25, gc=1e-3, l0=0.1)
+    G = np.array([[0.01, 0.004, -0.002], [0.003, -0.006, 0.001], [0.002, 0.005, 0.008]])[:rank, :rank]
+    pf, pf0 = 0.35, 0.2
+    st = np.zeros(coords.shape[0] * nd); st0 = st.copy()
+    st.reshape(-1, nd)[:, :rank] = coords @ G.T
+    st.reshape(-1, nd)[:, rank] = pf
+    st0.reshape(-1, nd)[:, rank] = pf0
+    jac, fv = po.arc_func(cfg, coords, conn, st, st0)
+    eps_t = 0.5 * (G + G.T)
+    eps = ([eps_t[0, 0], eps_t[1, 1], 0.0, 2 * eps_t[0, 1]] if rank == 2 else
+           [eps_t[0, 0], eps_t[1, 1], eps_t[2, 2], 2 * eps_t[0, 1], 2 * eps_t[1, 2], 2 * eps_t[2, 0]])
+    g, dg, _ = po.degradation(cfg, pf)
+    g0, _, _ = po.degradation(cfg, pf0)
+    _, _, Psi, _ = po.material_update(cfg, rank, np.array(eps), g)
+    V = 2.0 * 1.5 if rank == 2 else 1.0 * 2.0 * 1.5
+    assert abs(fv - V * (g0 - g) * Psi) < 1e-12 * abs(fv)
+    J = jac.reshape(-1, nd)
+    assert abs(J[:, rank].sum() + V * dg * Psi) < 1e-12 * abs(V * dg * Psi)
+    for i in range(rank):
+        assert abs(J[:, i].sum()) < 1e-12 * np.abs(J[:, i]).sum()
