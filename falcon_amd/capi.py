@@ -54,7 +54,7 @@ EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_
            "fa_assemble", "fa_assemble_noalloc", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
            "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum", "fa_strain_table", "fa_stress_table",
            "fa_pattern_device32", "fa_device", "fa_cons_create", "fa_cons_destroy", "fa_cons_set_rvalues", "fa_cons_eliminate",
-           "fa_cons_eval_masters", "fa_cons_eval_slaves", "fa_residual", "fa_arc_func"]
+           "fa_cons_eval_masters", "fa_cons_eval_slaves", "fa_residual", "fa_arc_func", "fa_output_data"]
 
 _lib = None
 
@@ -98,6 +98,7 @@ def lib():
         L.fa_cons_eval_slaves.argtypes = [vp, vp, vp]
         L.fa_residual.argtypes = [vp] * 11
         L.fa_arc_func.argtypes = [vp] * 6
+        L.fa_output_data.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
         ip = C.POINTER(C.c_int32)
         L.fa_shape_info.argtypes = [C.c_int32, ip, ip, ip]
         L.fa_shape_tables.argtypes = [C.c_int32, vp, vp, vp]
@@ -234,6 +235,16 @@ class Assembler:
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         _check(lib().fa_stress_table(self.h, table.data_ptr(), weights.data_ptr(), stream))
+
+    def output_data(self, cols, table, weights, stream=None):
+        """getOutputData_ (PhaseFractureModel.cpp:1408-1508): columns `cols` of [strain.tensor | stress.tensor]."""
+        import torch
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        assert table.is_cuda and weights.is_cuda and table.dtype == torch.float64 and weights.dtype == torch.float64
+        assert table.is_contiguous() and table.numel() == self.nnode * cols.size and weights.numel() == self.nnode
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().fa_output_data(self.h, cols.size, _np_ptr(cols), table.data_ptr(), weights.data_ptr(), stream))
 
     def arc_func(self, state, state0, jac10, fe_dissipation=None, stream=None):
         """getArcFunc_ (PhaseFractureModel.cpp:844-1063): fills jac10, returns the device scalar FE_DISSIPATION."""

@@ -365,6 +365,7 @@ struct fa_ctx {
           *d_prec = nullptr, *d_prun = nullptr;
   double* d_hist[2] = { nullptr, nullptr };   // [0] preHist_, [1] newHist_
   double* d_strain = nullptr; double* d_err_part = nullptr;
+  double* d_out_tmp = nullptr;         // fa_output_data: strain and stress tables + weights before the column filter
   double* d_arc_part = nullptr;        // fa_arc_func: per-workgroup partial sums of FE_DISSIPATION
   int32_t* d_row_ptr32 = nullptr;      // fa_pattern_device32: the offsets as 32-bit integers, made on first request
   // staging for fa_assemble_host
@@ -382,7 +383,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
   if (!c) return;
   DeviceGuard guard(c->prob.device);
   void* ptrs[] = { c->d_conn, c->d_coords, c->d_row_ptr, c->d_col_idx, c->d_node_dofs, c->d_n2e_ptr, c->d_n2e_ent,
-                   c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part, c->d_row_ptr32, c->d_arc_part,
+                   c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part, c->d_row_ptr32, c->d_arc_part, c->d_out_tmp,
                    c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err,
                    c->d_pn_ptr, c->d_pe_ptr, c->d_pr_ptr, c->d_pnode, c->d_poff, c->d_prec, c->d_prun,
                    c->d_tinfo, c->d_tnodes, c->d_telems, c->d_tconn, c->d_tpairs, c->d_tents,
@@ -1297,7 +1298,52 @@ extern "C" fa_status fa_stress_table(fa_ctx* c, double* table, double* weights, 
   return FA_OK;
 }
 
+// table[n][j] += (strain | stress)[n][cols[j]]: point-value columns 0..str-1 are the strain, str..2 str-1 the stress
+__global__ void output_split_filter_kernel(int64_t nnode, int str, int ncols, const int32_t* __restrict__ cols,
+                                           const double* __restrict__ tstrain, const double* __restrict__ tstress,
+                                           const double* __restrict__ wtmp, double* __restrict__ table,
+                                           double* __restrict__ weights) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nnode) return;
+  for (int j = 0; j < ncols; j++) {
+    const int cj = cols[j];
+    table[n * ncols + j] += (cj < str) ? tstrain[n * str + cj] : tstress[n * str + (cj - str)];
+  }
+  weights[n] += wtmp[n];
+}
+
+// getOutputData_ (PhaseFractureModel.cpp:1408-1508): strain.tensor and stress.tensor columns, filtered
+extern "C" fa_status fa_output_data(fa_ctx* c, int32_t ncols, const int32_t* cols, double* table, double* weights, void* stream) {
+  if (!c || !table || !weights || ncols < 0 || (ncols > 0 && !cols)) return fail(FA_ERR_ARG, "bad argument");
+  if (!c->d_strain) return fail(FA_ERR_ARG, "no strain cache: assemble with FA_STORE_STRAIN first");
+  const int str = c->str, ntmp = 2 * str;
+  if (ncols > ntmp) return fail(FA_ERR_ARG, "fa_output_data: %d columns requested, the point values have %d", ncols, ntmp);
+  for (int j = 0; j < ncols; j++)
+    if (cols[j] < 0 || cols[j] >= ntmp) return fail(FA_ERR_ARG, "fa_output_data: column %d out of range [0, %d)", cols[j], ntmp);
+  FA_ON_DEVICE(c->prob.device);
+  if (c->nnode == 0) return FA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nn = (size_t)c->nnode;
+  // layout of the scratch: [nnode][2 str] interleaved table, [nnode] weights, [nnode] second weights, 2 str column ids
+  if (!c->d_out_tmp) HIP_TRY(hipMalloc((void**)&c->d_out_tmp, sizeof(double) * (nn * (ntmp + 2) + 16)));
+  double* tstrain = c->d_out_tmp;                      // [nnode][str]
+  double* tstress = tstrain + nn * str;                // [nnode][str]
+  double* w1 = tstress + nn * str; double* w2 = w1 + nn;
+  int32_t* dcols = (int32_t*)(w2 + nn);
+  HIP_TRY(hipMemsetAsync(c->d_out_tmp, 0, sizeof(double) * nn * (ntmp + 2), st));
+  if (ncols > 0) HIP_TRY(hipMemcpyAsync(dcols, cols, sizeof(int32_t) * ncols, hipMemcpyHostToDevice, st));
+  fa_status rc = fa_strain_table(c, tstrain, w1, stream);
+  if (rc != FA_OK) return rc;
+  if ((rc = fa_stress_table(c, tstress, w2, stream)) != FA_OK) return rc;
+  hipLaunchKernelGGL(output_split_filter_kernel, dim3((unsigned)((c->nnode + 255) / 256)), dim3(256), 0, st, c->nnode, str, ncols,
+                     dcols, tstrain, tstress, w1, table, weights);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));                   // cols is a host array the caller may reuse
+  return FA_OK;
+}
+
 // getArcFunc_ (PhaseFractureModel.cpp:844-1063)
+extern "C"// getArcFunc_ (PhaseFractureModel.cpp:844-1063)
 extern "C" fa_status fa_arc_func(fa_ctx* c, const double* state, const double* state0, double* jac10, double* fe_dissipation,
                                  void* stream) {
   if (!c || !state || !state0 || !jac10 || !fe_dissipation) return fail(FA_ERR_ARG, "null argument");

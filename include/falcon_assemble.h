@@ -182,6 +182,14 @@ fa_status fa_strain_table(fa_ctx* ctx, double* table, double* weights, void* str
  * degradation (`update(stressIp, stiff, strainIp, gphiEx, ipoint)`), all str components (2-D: xx, yy, zz, xy). */
 fa_status fa_stress_table(fa_ctx* ctx, double* table, double* weights, void* stream);
 
+/* getOutputData_ (PhaseFractureModel.cpp:1408-1508): per Gauss point the values [strain.tensor | stress.tensor]
+ * (2 str entries: 8 in 2-D, 12 in 3-D; TbFiller's announce order, :1424-1425), the stress from the material update with
+ * the cached strain and degradation (:1482-1486); the columns cols[0..ncols) of them (TbFiller's filter, i2table,
+ * :1438-1439,:1492; host array) are extrapolated with the shape functions and ADDED to table (device, [nnode][ncols]),
+ * the shape-function sums to weights (device, [nnode]) -- once per element, as :1497-1506 do.  Needs a strain cache
+ * (FA_STORE_STRAIN).  The context keeps a scratch of nnode * (2 str + 2) doubles after the first call. */
+fa_status fa_output_data(fa_ctx* ctx, int32_t ncols, const int32_t* cols, double* table, double* weights, void* stream);
+
 /* getArcFunc_ (PhaseFractureModel.cpp:844-1063; ArclenActions::GET_ARC_FUNC of the dissipation-based
  * arc-length solver, TSArclenModule.cpp:612-641): the same Gauss-point loop as getMatrix_ with other outputs --
  *     jac10 (device, ndof doubles; zeroed and filled, :870,:1055-1056) = d(dissipation)/d(state)

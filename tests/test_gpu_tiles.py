@@ -194,6 +194,46 @@ def test_stress_table_matches_get_stress(shape, mesh, model, material, state):
     assert np.abs(weights.cpu().numpy() - wr).max() < 1e-12 * np.abs(wr).max()
 
 
+@pytest.mark.parametrize("shape,mesh,material,cols", [
+    (capi.QUAD4_G2, lambda: meshgen.grid_quad4(13, 9), capi.AMOR_PHASE, [5, 4]),            # vtk.data = "stress_yy | stress_xx"
+    (capi.QUAD4_G2, lambda: meshgen.grid_quad4(8, 7), capi.MIEHE_PHASE, list(range(8))),
+    (capi.HEX8_G2, lambda: meshgen.grid_hex8(4, 4, 3), capi.BOURDIN_PHASE, [0, 7, 11, 3])])
+def test_output_data_matches_get_output_data(shape, mesh, material, cols):
+    """getOutputData_ (PhaseFractureModel.cpp:1408-1508): the filtered [strain.tensor | stress.tensor] columns extrapolated
+    to the nodes, added to the table, weights added once per element; against the oracle's two element loops."""
+    import torch
+    coords, conn = mesh()
+    coords = meshgen.distort(coords, conn, 0.05, 6)
+    rank = coords.shape[1]
+    nd = rank + 1
+    kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2)
+    asm = capi.Assembler(shape, capi.PHASE_FRACTURE, material, coords, conn, **kw)
+    dev = torch.device("cuda", 0)
+    st = meshgen.smooth_state(coords, nd, seed=4, amp=5e-3, noise=1e-4, l0=0.3)
+    st[0::nd] -= 8e-3 * coords[:, 0]
+    f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+    table = torch.full((asm.nnode, len(cols)), 0.5, dtype=torch.float64, device=dev)
+    weights = torch.full((asm.nnode,), 0.25, dtype=torch.float64, device=dev)
+    with pytest.raises(capi.FaError, match="FA_STORE_STRAIN"):
+        asm.output_data(cols, table, weights)
+    asm.assemble(torch.from_numpy(st).to(dev), None, f, flags=capi.OVERWRITE | capi.STORE_STRAIN)
+    asm.output_data(cols, table, weights)
+    torch.cuda.synchronize()
+    with pytest.raises(capi.FaError, match="out of range"):
+        asm.output_data([99], table[:, :1].contiguous(), weights)
+    cfg = po.make_config(shape, capi.PHASE_FRACTURE, material, **kw)
+    rp, ci = asm.pattern()
+    ref = po.assemble(cfg, coords, conn, rp, ci, st, want_K=False, want_strain=True)
+    te, we = po.strain_table(shape, coords.shape[0], conn, ref["strain"])
+    ts, ws = po.stress_table(cfg, coords.shape[0], conn, ref["strain"])
+    both = np.concatenate([te, ts], axis=1)[:, cols]
+    got = table.cpu().numpy() - 0.5
+    for j in range(len(cols)):
+        scale = np.abs(both[:, j]).max()
+        assert np.abs(got[:, j] - both[:, j]).max() <= 1e-12 * max(scale, 1e-300)
+    assert np.abs(weights.cpu().numpy() - 0.25 - we).max() < 1e-12 * np.abs(we).max()
+
+
 @pytest.mark.parametrize("shape,mesh", [(capi.HEX8_G2, lambda: meshgen.grid_hex8(6, 5, 5)), (capi.QUAD4_G2, lambda: meshgen.grid_quad4(20, 17)),
                                         (capi.TRI6_G3, lambda: meshgen.grid_tri6(9, 8))])
 def test_value_array_that_is_only_8_byte_aligned(shape, mesh):
