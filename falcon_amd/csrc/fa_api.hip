@@ -55,6 +55,8 @@ namespace {
 struct DebugOptions {
   int  tiles = -1;        // FA_TILES=0|1: tile kernel off / on for every shape (-1: per-shape default)
   int  tile_order = -1;   // FA_TILE_ORDER=0|1: pair lanes count-sorted with shared (a,b)/(b,a) lanes | row order
+  int  tile_sym = -1;     // FA_TILE_SYM=0|1: one pair lane per unordered node pair across tiles off / on
+  int  tile_split = -1;   // FA_TILE_SPLIT=n: pairs spanning more than n elements are shared by 2 or 4 lanes (0: off)
   int  tile_big = -1;     // FA_TILE_BIG=0|1: two 512-thread workgroups per CU | one of 1024 threads
   int  emat = -1;         // FA_EMAT=0|1: element-matrix tile kernel (Quad4 / Triangle3) off / on
   int  fvec = -1;         // FA_FVEC=0|1: force-vector kernel (GET_INT_VECTOR passes of Quad4 / Triangle3) off / on
@@ -72,7 +74,7 @@ struct DebugOptions {
   static DebugOptions from_env() {
     DebugOptions o;
     auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1);
+    o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_split = geti("FA_TILE_SPLIT", -1);
     o.emat = geti("FA_EMAT", -1); o.emat_lds = geti("FA_EMAT_LDS", 0); o.emat_lpe = geti("FA_EMAT_LPE", 0);
     o.emat_lpe_f = geti("FA_EMAT_LPE_F", 0); o.fvec = geti("FA_FVEC", -1); o.fvec_blk = geti("FA_FVEC_BLK", 0);
     o.persist = geti("FA_PERSIST", -1);
@@ -821,12 +823,18 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       // geometry: two 512-thread workgroups per CU with 80 KB each; element slots of >= kTileBigSlot doubles (27-point
       // Hex20, general tangents in 3-D) get one 1024-thread workgroup with the whole LDS (Hex20 Gauss3^3 at 64^3: 8.8
       // against 10.9 ms)
-      const int recw = fa::tile_rec_doubles(rank, c->fam, keepK);
+      const int recw = fa::tile_rec_doubles(rank, c->fam, keepK, npe);
       const bool big = rank == 3 && (dbg.tile_big >= 0 ? dbg.tile_big != 0 : fa::tile_slot_doubles(sh.nip, recw) >= fa::kTileBigSlot);
       P.tile_block = big ? fa::kTileBlockBig : fa::kTileBlock;
+      // one lane per unordered node pair across tiles (TileOpts::sym_all) unless the lanes are in row order
+      fa::TileOpts topt;
+      topt.sym_all = !row_order && (dbg.tile_sym >= 0 ? dbg.tile_sym != 0 : true);
+      P.tile_sym = topt.sym_all ? 1 : 0;
+      topt.split = row_order ? 0 : (dbg.tile_split >= 0 ? dbg.tile_split : 2);
+      P.tile_split = topt.split > 0 ? 1 : 0;
       c->tile_path = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
                                      nb_ptr.data(), nb.data(), recw, fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0),
-                                     big ? fa::kTileLdsBig : fa::kTileLds, P.tile_block, row_order, ts);
+                                     big ? fa::kTileLdsBig : fa::kTileLds, P.tile_block, row_order, ts, topt);
       if (c->tile_path) { c->ntile3 = ts.ntile; P.ntile3 = ts.ntile; P.tile_lds = ts.lds_bytes; }
       // GET_INT_VECTOR passes keep no records, so a tile set sized for GET_MATRIX0 pays its Gauss-point redundancy for
       // nothing: measured faster than the row / cooperative kernels up to ~3 evaluations per point (Hex20 Gauss3: 5)

@@ -65,9 +65,15 @@ constexpr int kTileBlockBig = 1024, kTileLdsBig = 163000, kTileBigSlot = 200;
 // doubles of one Gauss-point record: J^-1, w det J, tangent (3 isotropic coefficients or the packed symmetric D;
 // nothing for Hooke, whose tangent is a constant),
 // c1 for phase-field families, sigma+ / g' / loading g' when the off-diagonal blocks are kept
-constexpr int tile_rec_doubles(int rank, int fam, bool keep) {
+#ifndef FA_TILE_GREC
+#define FA_TILE_GREC 0
+#endif
+// Hex8: the record holds the NPE physical shape gradients instead of J^-1 (the pair lanes then read 2 x 3 doubles per
+// point instead of 9 + 2 x 3 and skip the 18 multiply-adds that rebuild the gradients)
+constexpr bool tile_grad_records(int rank, int npe) { return FA_TILE_GREC && rank == 3 && npe == 8; }
+constexpr int tile_rec_doubles(int rank, int fam, bool keep, int npe = 0) {
   const int S = (rank == 2) ? 3 : 6;
-  return rank * rank + 1 + (fam == FAM_PF_MIEHE ? S * (S + 1) / 2 : (fam != FAM_LE ? 3 : 0)) + (fam != FAM_LE ? 1 : 0) + (keep ? S + 2 : 0);
+  return (tile_grad_records(rank, npe) ? npe * rank : rank * rank) + 1 + (fam == FAM_PF_MIEHE ? S * (S + 1) / 2 : (fam != FAM_LE ? 3 : 0)) + (fam != FAM_LE ? 1 : 0) + (keep ? S + 2 : 0);
 }
 // doubles of one element slot (nip records): odd, so that lanes reading the same field of different slots spread
 // over the LDS banks
@@ -149,7 +155,7 @@ struct Params {
   double*        f;
   // ---- sizes / switches ----
   int64_t nnode, nel;
-  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2, ntile3, tile_lds, tile_stage, tile_block, rec_padded, emat_lpe, fvec_val, conn_stride, st_maxn, st_maxe, persistent;
+  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2, ntile3, tile_lds, tile_stage, tile_block, tile_sym, tile_split, rec_padded, emat_lpe, fvec_val, conn_stride, st_maxn, st_maxe, persistent;
   int32_t cnt[4];            // entries per neighbour node in a row of dof type i
   int32_t off[4][4];         // offset of column type j inside that group, -1 if not in the pattern
   // ---- constants ----

@@ -33,9 +33,10 @@ template <class SH, int FAM, bool KEEP>
 struct TileRec {                                        // offsets (doubles) inside one Gauss-point record
   static constexpr int R = SH::RANK, S = SH::S;
   static constexpr bool PF = (FAM != FAM_LE), GEN = (FAM == FAM_PF_MIEHE);
-  static constexpr int O_INV = 0, O_W = R * R, O_D = O_W + 1, NDC = GEN ? S * (S + 1) / 2 : (PF ? 3 : 0);   // Hooke: the tangent is a constant of the launch
+  static constexpr bool GREC = tile_grad_records(R, SH::NPE);           // gradients of all nodes instead of J^-1
+  static constexpr int O_INV = 0, O_W = GREC ? SH::NPE * R : R * R, O_D = O_W + 1, NDC = GEN ? S * (S + 1) / 2 : (PF ? 3 : 0);   // Hooke: the tangent is a constant of the launch
   static constexpr int O_C1 = O_D + NDC, O_SP = O_C1 + (PF ? 1 : 0), W = O_SP + (KEEP ? S + 2 : 0);
-  static_assert(W == tile_rec_doubles(R, FAM, KEEP), "host and device disagree on the record width");
+  static_assert(W == tile_rec_doubles(R, FAM, KEEP, SH::NPE), "host and device disagree on the record width");
 };
 
 template <class SH, int FAM, bool WANT_K, bool KEEP, class SP, int BLK>
@@ -62,9 +63,10 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   double* sExt = sNod + n_all * NODW;                 // phi of state0 / state00 (stateExt_), Ext variants only
   const bool ext_state = PF && (SP::model(P) == 2 || SP::model(P) == 3 || SP::model(P) >= 5);
   double* sF   = sExt + (ext_state ? 2 * n_all : 0);
-  long long* sRow = reinterpret_cast<long long*>(sF + n_own * NDOF);   // first CSR entry of every owned node's first row
-  int* sDeg = reinterpret_cast<int*>(sRow + n_own);                    // neighbours of every owned node
-  double* sTab = reinterpret_cast<double*>(sRow + n_own) + (n_own + 1) / 2;
+  const int n_rows = P.tile_sym ? n_all : n_own;      // cross-tile mirror lanes also write rows of halo nodes
+  long long* sRow = reinterpret_cast<long long*>(sF + n_own * NDOF);   // first CSR entry of every (owned) node's first row
+  int* sDeg = reinterpret_cast<int*>(sRow + n_rows);                   // neighbours of every (owned) node
+  double* sTab = reinterpret_cast<double*>(sRow + n_rows) + (n_rows + 1) / 2;
   uint16_t* sConn = (uint16_t*)(sTab + TABN);
   const double* tabN = sTab;
   const double* tabD = sTab + NIP * NPE;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
     }
   }
   for (int i = tid; i < n_own * NDOF; i += BLK) sF[i] = 0.0;
-  for (int i = tid; i < n_own; i += BLK) {
+  for (int i = tid; i < n_rows; i += BLK) {
     const int64_t r0 = (int64_t)P.tnodes[node_off + i] * NDOF;
     const long long b0 = P.row_ptr[r0], b1 = P.row_ptr[r0 + 1];
     sRow[i] = b0; sDeg[i] = (P.cnt[0] > 0) ? (int)((b1 - b0) / P.cnt[0]) : 0;
@@ -155,6 +157,10 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
         for (int k = 0; k < RANK; k++) acc += tabD[(ip * NPE + a) * RANK + k] * inv[k][i];
         ga[i] = acc; ua[i] = nd[RANK + i];
       }
+      if constexpr (WANT_K && TR::GREC) {
+#pragma unroll
+        for (int i = 0; i < RANK; i++) sRec[s * SLOTW + ip * RW + TR::O_INV + a * RANK + i] = ga[i];
+      }
       if constexpr (RANK == 2) {                       // strain = B u (ShapeUtils.cpp:73-104)
         eps[0] += ga[0] * ua[0]; eps[1] += ga[1] * ua[1];
         eps[2] += ga[1] * ua[0]; eps[2] += ga[0] * ua[1];
@@ -191,10 +197,12 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
 
     if constexpr (WANT_K) {
     double* rec = sRec + s * SLOTW + ip * RW;
+    if constexpr (!TR::GREC) {
 #pragma unroll
-    for (int k = 0; k < RANK; k++)
+      for (int k = 0; k < RANK; k++)
 #pragma unroll
-      for (int i = 0; i < RANK; i++) rec[TR::O_INV + k * RANK + i] = inv[k][i];
+        for (int i = 0; i < RANK; i++) rec[TR::O_INV + k * RANK + i] = inv[k][i];
+    }
     rec[TR::O_W] = w;
     if constexpr (FAM == FAM_PF_MIEHE) {
       int q = 0;
@@ -250,8 +258,13 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
 
   // ---- phase 2: node-pair blocks of K1..K4 (PhaseFractureModel.cpp:713-722) ----
   if constexpr (WANT_K) {
-  const double* tab2N = tabN;
-  const double* tab2D = tabD;
+#ifndef FA_TILE_TAB_GLOBAL
+#define FA_TILE_TAB_GLOBAL 0
+#endif
+  // FA_TILE_TAB_GLOBAL=1 reads the shape tables of the pair lanes through the vector-memory path to take load off
+  // the LDS: measured slower (Hex8 100^3 3.94 against 3.47 ms, Hex20 64^3 11.2 against 8.75 ms) -- divergent 8-byte loads.
+  const double* __restrict__ tab2N = FA_TILE_TAB_GLOBAL ? P.tab : tabN;
+  const double* __restrict__ tab2D = FA_TILE_TAB_GLOBAL ? P.tab + NIP * NPE : tabD;
   // wave-private staging rows for the coalesced write-out of row-ordered lanes (P.tile_stage)
   double* stg = reinterpret_cast<double*>(sConn + ((n_el * NPE + 3) & ~3)) + (tid >> 6) * (64 * NDOF + 64);
   long long* stg_base = reinterpret_cast<long long*>(stg + 64 * NDOF);
@@ -290,10 +303,14 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
 #pragma unroll
         for (int i = 0; i < RANK; i++) {               // same expression as phase 1: the gradients are bit-identical
           double acca = 0.0, accb = 0.0;
+          if constexpr (TR::GREC) {
+            acca = rec[TR::O_INV + la * RANK + i]; accb = rec[TR::O_INV + lb * RANK + i];
+          } else {
 #pragma unroll
-          for (int k = 0; k < RANK; k++) {
-            acca += tab2D[(ip * NPE + la) * RANK + k] * rec[TR::O_INV + k * RANK + i];
-            accb += tab2D[(ip * NPE + lb) * RANK + k] * rec[TR::O_INV + k * RANK + i];
+            for (int k = 0; k < RANK; k++) {
+              acca += tab2D[(ip * NPE + la) * RANK + k] * rec[TR::O_INV + k * RANK + i];
+              accb += tab2D[(ip * NPE + lb) * RANK + k] * rec[TR::O_INV + k * RANK + i];
+            }
           }
           wga[i] = w * acca; gb[i] = accb; ga[i] = acca;
         }
@@ -334,6 +351,13 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
           Kuu[0][1] += (wga[0] * d1) * gb[1] + (wga[1] * d3) * gb[0];
           Kuu[1][0] += (wga[1] * d1) * gb[0] + (wga[0] * d3) * gb[1];
           Kuu[1][1] += (wga[1] * d0) * gb[1] + (wga[0] * d3) * gb[0];
+        } else if constexpr (!PF) {
+          // Hooke: the tangent is a constant of the launch, so only M = sum w g_a g_b^T is accumulated per point
+          // (9 multiply-adds); K1 = d1 M + d3 M^T + diag((d0 - d1 - d3) M_ii + d3 tr M) follows after the loops
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Kuu[i][j] += wga[i] * gb[j];
         } else {
           const double d0 = PF ? rec[TR::O_D] : P.hd0, d1 = PF ? rec[TR::O_D + 1] : P.hd1, d3 = PF ? rec[TR::O_D + 2] : P.hd3;
           const double dotp = wga[0] * gb[0] + wga[1] * gb[1] + wga[2] * gb[2];
@@ -384,6 +408,49 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
           }
         }
       }
+    }
+    // lane groups (TileOpts::split): the 2 or 4 adjacent lanes that share a pair add their partial blocks with DPP
+    // quad permutes; the first lane of the group goes on to write
+    const int lg = P.tile_split ? (int)((pw.z >> 24) & 3u) : 0;
+    if (P.tile_split && __any(lg != 0)) {
+      auto dpp = [](double v, auto ctl) {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_mov_dpp(lo, decltype(ctl)::value, 0xF, 0xF, true);
+        hi = __builtin_amdgcn_mov_dpp(hi, decltype(ctl)::value, 0xF, 0xF, true);
+        return __hiloint2double(hi, lo);
+      };
+      auto gsum = [&](double& v) {
+        const double p1 = dpp(v, std::integral_constant<int, 0xB1>());      // quad_perm [1,0,3,2]
+        v += (lg >= 1) ? p1 : 0.0;
+        const double p2 = dpp(v, std::integral_constant<int, 0x4E>());      // quad_perm [2,3,0,1]
+        v += (lg >= 2) ? p2 : 0.0;
+      };
+#pragma unroll
+      for (int i = 0; i < RANK; i++) {
+#pragma unroll
+        for (int j = 0; j < RANK; j++) gsum(Kuu[i][j]);
+      }
+      if constexpr (PF) {
+        gsum(Kpp);
+        if constexpr (KEEP) {
+#pragma unroll
+          for (int i = 0; i < RANK; i++) { gsum(Kup[i]); gsum(Kpu[i]); gsum(Kup2[i]); gsum(Kpu2[i]); }
+        }
+      }
+    }
+    const bool leader = !P.tile_split || ((pw.z >> 26) & 3u) == 0;
+    if constexpr (!PF && RANK == 3) {                  // Hooke in 3-D: K1 from M (see above)
+      const double tr = Kuu[0][0] + Kuu[1][1] + Kuu[2][2];
+      double Kn[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+          Kn[i][j] = (i == j) ? (P.hd0 - P.hd3) * Kuu[i][i] + P.hd3 * tr : P.hd1 * Kuu[i][j] + P.hd3 * Kuu[j][i];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Kuu[i][j] = Kn[i][j];
     }
     // ---- the block's CSR entries: rows of a node, columns of its kp-th neighbour (canonical blocked layout) ----
     // first entry of row i of owned node io: the rows of a node follow each other, deg * cnt[i'] entries each
@@ -461,7 +528,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
       }
       continue;
     }
-    if (!active) continue;
+    if (!active || !leader) continue;
     emit(ia, kpos, blk);
     if (mirror) {
 #pragma unroll

@@ -38,6 +38,16 @@ struct TileOpts {
   int max_all = 0;          // > 0: at most this many nodes (owned + halo) per tile
   bool conn_pad4 = false;   // tconn rows padded to 4 entries (8 bytes per element: the persistent kernels fetch them with
                             // two 4-byte LDS-DMA loads)
+  bool sym_all = false;     // order 0 only: every unordered node pair {a, b} gets ONE lane, in the tile that owns the node
+                            // with the smaller id; the lane also writes the block (b, a) into b's rows, whether or not
+                            // this tile owns b (the tile holds every element with both nodes, so its sum is complete and
+                            // every entry of K still has exactly one writer).  Halves the pair work; the kernel then
+                            // needs the row bases of all tile nodes, not only the owned ones (12 bytes of LDS per node).
+  int split = 0;            // order 0 only, > 0: a pair that spans more than `split` elements is shared by 2 or 4 adjacent
+                            // lanes (its elements dealt out in runs), which add their partial blocks with DPP row
+                            // operations before the first of them writes: the lanes of a wave then do (nearly) equal
+                            // work instead of 8 / 4 / 2 / 1 elements.  Pair word 2: bits 24-25 log2(lanes of the
+                            // group), bits 26-27 index of this lane in its group.
   int fvec = 0;             // > 0: force-vector mode (fa_emat_impl.h, assemble_fvec): no element slots, no pair lanes; per
                             // element the slot ranks of its nodes, per owned node its valence (<= fvec)
 };

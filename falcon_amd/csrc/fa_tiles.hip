@@ -54,7 +54,7 @@ struct Cutter {                                        // greedy cut of the sort
 
   int64_t bytes(int64_t n_el, int64_t n_all, int64_t n_own) const {
     const int64_t slot = opts.fvec > 0 ? 0 : (opts.slot_doubles > 0 ? opts.slot_doubles : tile_slot_doubles(nip, rec_doubles));
-    return 8 * (n_el * slot + n_all * node_doubles + n_own * (opts.own_doubles + (opts.no_f_image ? 0 : ndofpn) + 2) + (opts.no_tab ? 0 : tabn)) + 2 * n_el * (opts.conn_pad4 ? 4 : npe) + 16 + extra_bytes;
+    return 8 * (n_el * slot + n_all * node_doubles + n_own * (opts.own_doubles + (opts.no_f_image ? 0 : ndofpn) + 2) + (opts.sym_all ? 2 * (n_all - n_own) : 0) + (opts.no_tab ? 0 : tabn)) + 2 * n_el * (opts.conn_pad4 ? 4 : npe) + 16 + extra_bytes;
   }
   // Tiles end where the Morton cell of 2^L codes ends (once half full) or where the LDS budget / counters say so.
   // Returns false if one node alone does not fit.  starts: first position of every tile in `order` (+ sentinel).
@@ -196,7 +196,10 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
     const int32_t* c = counts.data() + t * 5;
     T.max_own = std::max(T.max_own, c[0]); T.max_all = std::max(T.max_all, c[1]); T.max_el = std::max(T.max_el, c[2]);
   }
-  T.tpairs.assign((size_t)o_pair[ntile] * 4, 0); T.tents.assign((size_t)o_ent[ntile], 0);
+  const bool split_mode = opts.split > 0 && order_mode == 0;
+  std::vector<std::vector<uint32_t>> split_pairs;      // split mode: the lane count of a tile is known only after its pairs are cut
+  if (split_mode) split_pairs.resize((size_t)ntile); else T.tpairs.assign((size_t)o_pair[ntile] * 4, 0);
+  T.tents.assign((size_t)o_ent[ntile], 0);
   T.point_redundancy = (double)o_el[ntile] / (double)nel;
   if (opts.fvec > 0) { T.eslot.assign((size_t)o_el[ntile], 0); T.nval.assign((size_t)o_node[ntile], 0); }
 
@@ -266,7 +269,12 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
           PairTmp q; q.first = (uint32_t)ent.size(); q.cnt = 0; q.w2 = 0;
           const int ib = find_local(b);
           if (opts.diag_only && ib != ia) continue;
-          if (order_mode == 0 && ib >= 0 && ib < n_own && ib != ia) {   // both owned: one lane for (a, b) and (b, a)
+          if (order_mode == 0 && opts.sym_all && ib != ia) {            // one lane per unordered pair, in the tile of the smaller id
+            if (b < a) continue;
+            const int32_t* lo2 = nb + nb_ptr[b]; const int32_t* hi2 = nb + nb_ptr[b + 1];
+            const uint32_t k2 = (uint32_t)(std::lower_bound(lo2, hi2, a) - lo2);
+            q.w2 = (uint32_t)ib | (k2 << 16) | 0x80000000u;
+          } else if (order_mode == 0 && ib >= 0 && ib < n_own && ib != ia) {   // both owned: one lane for (a, b) and (b, a)
             if (ib < ia) continue;
             const int32_t* lo2 = nb + nb_ptr[b]; const int32_t* hi2 = nb + nb_ptr[b + 1];
             const uint32_t k2 = (uint32_t)(std::lower_bound(lo2, hi2, a) - lo2);
@@ -307,10 +315,38 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
           return (ent[x.first] & 0xFFFFu) < (ent[y.first] & 0xFFFFu);
         });
       }
-      ti[6] = (int32_t)pt.size();
-      uint32_t* tp = T.tpairs.data() + o_pair[t] * 4;
       uint32_t* tq = T.tents.data() + o_ent[t];
       uint32_t run = 0;
+      if (split_mode) {
+        // groups of 4 / 2 / 1 lanes, largest groups first (a group never straddles a wave), then by elements per lane
+        auto lanes_of = [&](uint32_t cnt) { return cnt > 2u * opts.split ? 4u : (cnt > (uint32_t)opts.split ? 2u : 1u); };
+        std::stable_sort(pt.begin(), pt.end(), [&](const PairTmp& x, const PairTmp& y) {
+          const uint32_t gx = lanes_of(x.cnt), gy = lanes_of(y.cnt);
+          if (gx != gy) return gx > gy;
+          const uint32_t px = (x.cnt + gx - 1) / gx, py = (y.cnt + gy - 1) / gy;
+          if (px != py) return px > py;
+          if (x.cnt == 0 || y.cnt == 0) return false;
+          return (ent[x.first] & 0xFFFFu) < (ent[y.first] & 0xFFFFu);
+        });
+        std::vector<uint32_t>& tp = split_pairs[(size_t)t];
+        tp.clear();
+        for (size_t i = 0; i < pt.size(); i++) {
+          const uint32_t g = lanes_of(pt[i].cnt), lg = g == 4 ? 2u : (g == 2 ? 1u : 0u), per = (pt[i].cnt + g - 1) / g;
+          for (uint32_t j = 0; j < g; j++) {
+            const uint32_t b0 = std::min(pt[i].cnt, j * per), b1 = std::min(pt[i].cnt, (j + 1) * per), c = b1 - b0;
+            tp.push_back(((pt[i].w0) & 0x00FFFFFFu) | (c << 24));
+            tp.push_back(run + b0);
+            tp.push_back(pt[i].w2 | (lg << 24) | (j << 26));
+            tp.push_back(c ? ent[pt[i].first + b0] : 0u);
+          }
+          for (uint32_t k = 0; k < pt[i].cnt; k++) tq[run + k] = ent[pt[i].first + k];
+          run += pt[i].cnt;
+        }
+        ti[6] = (int32_t)(tp.size() / 4);
+        continue;
+      }
+      ti[6] = (int32_t)pt.size();
+      uint32_t* tp = T.tpairs.data() + o_pair[t] * 4;
       for (size_t i = 0; i < pt.size(); i++) {
         tp[4 * i] = pt[i].w0; tp[4 * i + 1] = run; tp[4 * i + 2] = pt[i].w2; tp[4 * i + 3] = pt[i].cnt ? ent[pt[i].first] : 0u;
         for (uint32_t k = 0; k < pt[i].cnt; k++) tq[run + k] = ent[pt[i].first + k];
@@ -318,6 +354,21 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
       }
     }
   });
+  if (split_mode) {                                    // concatenate the tiles' lane records
+    int64_t total = 0;
+    for (int64_t t = 0; t < ntile; t++) {
+      T.tinfo[(size_t)t * kTileInfo + 5] = (int32_t)total;
+      total += (int64_t)split_pairs[(size_t)t].size() / 4;
+      if (total * 4 > lim) return false;
+    }
+    T.tpairs.assign((size_t)total * 4, 0);
+    par_for(ntile, [&](int64_t tb, int64_t te) {
+      for (int64_t t = tb; t < te; t++) {
+        const std::vector<uint32_t>& v = split_pairs[(size_t)t];
+        if (!v.empty()) std::memcpy(T.tpairs.data() + (size_t)T.tinfo[(size_t)t * kTileInfo + 5] * 4, v.data(), v.size() * 4);
+      }
+    });
+  }
   return true;
 }
 
