@@ -57,6 +57,7 @@ struct DebugOptions {
   int  tile_order = -1;   // FA_TILE_ORDER=0|1: pair lanes count-sorted with shared (a,b)/(b,a) lanes | row order
   int  tile_sym = -1;     // FA_TILE_SYM=0|1: one pair lane per unordered node pair across tiles off / on
   int  tile_split = -1;   // FA_TILE_SPLIT=n: pairs spanning more than n elements are shared by 2 or 4 lanes (0: off)
+  int  tile_sort = -1;    // FA_TILE_SORT=0|1: owned nodes of a tile in Morton order | ascending node id
   int  tile_big = -1;     // FA_TILE_BIG=0|1: two 512-thread workgroups per CU | one of 1024 threads
   int  emat = -1;         // FA_EMAT=0|1: element-matrix tile kernel (Quad4 / Triangle3) off / on
   int  fvec = -1;         // FA_FVEC=0|1: force-vector kernel (GET_INT_VECTOR passes of Quad4 / Triangle3) off / on
@@ -74,7 +75,7 @@ struct DebugOptions {
   static DebugOptions from_env() {
     DebugOptions o;
     auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_split = geti("FA_TILE_SPLIT", -1);
+    o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_sort = geti("FA_TILE_SORT", -1); o.tile_split = geti("FA_TILE_SPLIT", -1);
     o.emat = geti("FA_EMAT", -1); o.emat_lds = geti("FA_EMAT_LDS", 0); o.emat_lpe = geti("FA_EMAT_LPE", 0);
     o.emat_lpe_f = geti("FA_EMAT_LPE_F", 0); o.fvec = geti("FA_FVEC", -1); o.fvec_blk = geti("FA_FVEC_BLK", 0);
     o.persist = geti("FA_PERSIST", -1);
@@ -887,8 +888,9 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       const int nodw = fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0);
       c->fvec.block = (dbg.fvec_blk == 128 || dbg.fvec_blk == 192 || dbg.fvec_blk == 256 || dbg.fvec_blk == 320) ? dbg.fvec_blk : 192;
       fa::TileOpts o;
-      o.no_tab = true; o.no_f_image = true; o.fvec = maxval; o.own_doubles = maxval * nd; o.max_el = c->fvec.block;
+      o.no_tab = true; o.no_f_image = true; o.fvec = maxval; o.own_doubles = (maxval * nd) | 1; o.max_el = c->fvec.block;
       o.conn_pad4 = true; o.max_all = 2 * c->fvec.block;
+      o.sort_local = dbg.tile_sort >= 0 ? dbg.tile_sort != 0 : true;
       c->fvec.ok = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
                                    nb_ptr.data(), nb.data(), 0, nodw, 48 * 1024, c->fvec.block, false, tsV, o);
       if (c->fvec.ok) {
@@ -899,7 +901,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
         if (model_ok && (dbg.persist > 0) && (c->fvec.block == 192 || c->fvec.block == 256)) {
           c->fvec.maxn = (tsV.max_all + 63) / 64 * 64; c->fvec.maxe = (tsV.max_el + 63) / 64 * 64;
           const bool hist = p->model != FA_LINEAR_ELASTICITY;
-          c->fvec.plds = 2 * fa::stage_bytes_host(pf, sh.nip, c->fvec.maxn, c->fvec.maxe, hist) + tsV.max_own * maxval * nd * 8;
+          c->fvec.plds = 2 * fa::stage_bytes_host(pf, sh.nip, c->fvec.maxn, c->fvec.maxe, hist) + tsV.max_own * ((maxval * nd) | 1) * 8;
           c->fvec.persistent = c->fvec.plds <= 160 * 1024 && c->fvec.maxe <= c->fvec.block;
         }
       }

@@ -518,8 +518,11 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
   double* sNod = smem;
   double* sExt = sNod + n_all * NODW;
   const bool ext_state = PF && (SP::model(P) == 2 || SP::model(P) == 3 || SP::model(P) >= 5);
-  double* sBuf = sExt + (ext_state ? 2 * n_all : 0);   // [n_own][V][NDOF]
-  int* sNode = reinterpret_cast<int*>(sBuf + n_own * V * NDOF);
+  // [n_own][V][NDOF], the rows of a node padded to an odd number of doubles: consecutive nodes then start on 16
+  // different bank pairs (12 doubles per node = 4 starting banks = 4-way conflicts on every write of phase 1)
+  const int SB = (V * NDOF) | 1;
+  double* sBuf = sExt + (ext_state ? 2 * n_all : 0);
+  int* sNode = reinterpret_cast<int*>(sBuf + n_own * SB);
   uint16_t* sConn = reinterpret_cast<uint16_t*>(sNode + n_own);
   const int CS = P.conn_stride;                        // tconn entries per element (NPE, or 4 when padded)
   uint8_t* sVal = reinterpret_cast<uint8_t*>(sConn + n_el * CS);
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
 #pragma unroll
     for (int a = 0; a < NPE; a++) {
       if (li[a] < n_own) {
-        double* dst = sBuf + (li[a] * V + (int)((es >> (8 * a)) & 0xFFu)) * NDOF;
+        double* dst = sBuf + li[a] * SB + (int)((es >> (8 * a)) & 0xFFu) * NDOF;
 #pragma unroll
         for (int i = 0; i < RANK; i++) dst[i] = A.fu[a][i];
         if constexpr (PF) dst[RANK] = A.fp[a];
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
   for (int i = tid; i < n_own * NDOF; i += BLK) {
     const int ia = i / NDOF, c = i - ia * NDOF;
     const int val = (int)sVal[ia];
-    const double* src = sBuf + ia * V * NDOF + c;
+    const double* src = sBuf + ia * SB + c;
     double s = 0.0;
     for (int k = 0; k < val; k++) s += src[k * NDOF];
     const int64_t q = (int64_t)sNode[ia] * NDOF + c;
@@ -690,7 +693,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(3))) void a
   const int MAXN = P.st_maxn, MAXE = P.st_maxe, V = P.fvec_val;
   const bool hist_model = PF && (SP::model(P) == 1 || SP::model(P) >= 4);
   const StageLayout<SH, PF> L(MAXN, MAXE, hist_model);
-  double* sBuf = reinterpret_cast<double*>(lds + 2 * L.bytes);     // [n_own][V][NDOF]
+  const int SB = (V * NDOF) | 1;                       // see assemble_fvec
+  double* sBuf = reinterpret_cast<double*>(lds + 2 * L.bytes);     // [n_own][V][NDOF] + pad
 
   // tiles of this workgroup: XCD x = blockIdx % 8 owns one contiguous band of tiles
   const int nt = P.ntile3, perT = (nt + 7) >> 3, stride = (int)gridDim.x >> 3;
@@ -821,7 +825,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(3))) void a
 #pragma unroll
       for (int a = 0; a < NPE; a++) {
         if (li[a] < cur.n_own) {
-          double* dst = sBuf + (li[a] * V + (int)((es >> (8 * a)) & 0xFFu)) * NDOF;
+          double* dst = sBuf + li[a] * SB + (int)((es >> (8 * a)) & 0xFFu) * NDOF;
 #pragma unroll
           for (int i = 0; i < RANK; i++) dst[i] = A.fu[a][i];
           if constexpr (PF) dst[RANK] = A.fp[a];
@@ -834,7 +838,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(3))) void a
     for (int i = tid; i < cur.n_own * NDOF; i += BLK) {
       const int ia = i / NDOF, c = i - ia * NDOF;
       const int val = reinterpret_cast<const int*>(B + L.oNV)[ia];
-      const double* src = sBuf + ia * V * NDOF + c;
+      const double* src = sBuf + ia * SB + c;
       double s = 0.0;
       for (int k = 0; k < val; k++) s += src[k * NDOF];
       const int64_t q = (int64_t)reinterpret_cast<const int*>(B + L.oNID)[ia] * NDOF + c;

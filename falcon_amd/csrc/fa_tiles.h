@@ -43,6 +43,9 @@ struct TileOpts {
                             // this tile owns b (the tile holds every element with both nodes, so its sum is complete and
                             // every entry of K still has exactly one writer).  Halves the pair work; the kernel then
                             // needs the row bases of all tile nodes, not only the owned ones (12 bytes of LDS per node).
+  bool sort_local = false;  // owned nodes of a tile in ascending node id instead of Morton order: on meshes numbered row by
+                            // row the lanes of a wave then read consecutive LDS node slots (no bank conflicts) and the
+                            // staging reads / f writes run over consecutive global addresses
   int split = 0;            // order 0 only, > 0: a pair that spans more than `split` elements is shared by 2 or 4 adjacent
                             // lanes (its elements dealt out in runs), which add their partial blocks with DPP row
                             // operations before the first of them writes: the lanes of a wave then do (nearly) equal

@@ -205,7 +205,7 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
 
   // ---- fill ----
   par_for(ntile, [&](int64_t tb, int64_t te) {
-    std::vector<int32_t> els, halo;
+    std::vector<int32_t> els, halo, own_sorted;
     std::vector<std::pair<int32_t, int32_t>> lookup;   // (node, local index), sorted by node
     struct PairTmp { uint32_t w0, w2; uint32_t first, cnt; bool diag; };
     std::vector<PairTmp> pt; std::vector<uint32_t> ent;
@@ -213,6 +213,11 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
       const int32_t* c = counts.data() + t * 5;
       const int n_own = c[0], n_all = c[1], n_el = c[2];
       const int32_t* own = order.data() + starts[(size_t)t];
+      if (opts.sort_local) {
+        own_sorted.assign(own, own + n_own);
+        std::sort(own_sorted.begin(), own_sorted.end());
+        own = own_sorted.data();
+      }
       int32_t* ti = T.tinfo.data() + t * kTileInfo;
       ti[0] = (int32_t)o_node[t]; ti[1] = n_all; ti[2] = n_own; ti[3] = (int32_t)o_el[t]; ti[4] = n_el;
       ti[5] = (int32_t)o_pair[t]; ti[6] = c[3]; ti[7] = (int32_t)o_ent[t];
