@@ -58,6 +58,7 @@ struct DebugOptions {
   int  tile_sym = -1;     // FA_TILE_SYM=0|1: one pair lane per unordered node pair across tiles off / on
   int  tile_split = -1;   // FA_TILE_SPLIT=n: pairs spanning more than n elements are shared by 2 or 4 lanes (0: off)
   int  tile_sort = -1;    // FA_TILE_SORT=0|1: owned nodes of a tile in Morton order | ascending node id
+  int  tile_fu = -1;      // FA_TILE_FU=0|1: 3-D elastic GET_MATRIX0 passes take f_int from the pair lanes (K u) off / on
   int  tile_big = -1;     // FA_TILE_BIG=0|1: two 512-thread workgroups per CU | one of 1024 threads
   int  emat = -1;         // FA_EMAT=0|1: element-matrix tile kernel (Quad4 / Triangle3) off / on
   int  fvec = -1;         // FA_FVEC=0|1: force-vector kernel (GET_INT_VECTOR passes of Quad4 / Triangle3) off / on
@@ -75,7 +76,7 @@ struct DebugOptions {
   static DebugOptions from_env() {
     DebugOptions o;
     auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_sort = geti("FA_TILE_SORT", -1); o.tile_split = geti("FA_TILE_SPLIT", -1);
+    o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_fu = geti("FA_TILE_FU", -1); o.tile_sort = geti("FA_TILE_SORT", -1); o.tile_split = geti("FA_TILE_SPLIT", -1);
     o.emat = geti("FA_EMAT", -1); o.emat_lds = geti("FA_EMAT_LDS", 0); o.emat_lpe = geti("FA_EMAT_LPE", 0);
     o.emat_lpe_f = geti("FA_EMAT_LPE_F", 0); o.fvec = geti("FA_FVEC", -1); o.fvec_blk = geti("FA_FVEC_BLK", 0);
     o.persist = geti("FA_PERSIST", -1);
@@ -832,6 +833,11 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       topt.sym_all = !row_order && (dbg.tile_sym >= 0 ? dbg.tile_sym != 0 : true);
       P.tile_sym = topt.sym_all ? 1 : 0;
       topt.split = row_order ? 0 : (dbg.tile_split >= 0 ? dbg.tile_split : 2);
+      // grouped pair lanes: the kernel's record format is fixed at compile time, so the tiling must follow it
+      topt.group = fa::tile_group(rank, c->fam);
+      topt.write_order = getenv("FA_TILE_WORDER") != nullptr && atoi(getenv("FA_TILE_WORDER")) != 0;
+      P.tile_fu = (topt.group > 1 && (dbg.tile_fu >= 0 ? dbg.tile_fu != 0 : true)) ? 1 : 0;   // capability; decided per call
+      if (topt.group > 1 && !topt.sym_all) return fail(FA_ERR_UNSUPPORTED, "FA_TILE_SYM=0 / row order is not available for the grouped pair lanes of the 3-D elastic kernels");
       P.tile_split = topt.split > 0 ? 1 : 0;
       c->tile_path = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
                                      nb_ptr.data(), nb.data(), recw, fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0),
@@ -845,6 +851,17 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
                 "Gauss-point redundancy %.3f\n", c->tile_path ? "ok" : "not built", ts.ntile,
                 ts.ntile ? (double)nnode / ts.ntile : 0.0, ts.ntile ? (double)ts.telems.size() / ts.ntile : 0.0,
                 ts.lds_bytes, ts.point_redundancy);
+      if (dbg.verbose && topt.group > 1) {
+        int64_t lanes = (int64_t)ts.tpairs.size() / 4, nbsum = 0, work = 0, hist[5] = { 0, 0, 0, 0, 0 };
+        for (int64_t i = 0; i < lanes; i++) {
+          const uint32_t x = ts.tpairs[(size_t)i * 4];
+          const int nbq = (int)((x >> 16) & 0xFF), cq = (int)(x >> 24);
+          nbsum += nbq; work += (int64_t)nbq * cq; hist[std::min(nbq, 4)]++;
+        }
+        fprintf(stderr, "[falcon_assemble] grouped pair lanes: %lld lanes, %.2f neighbours per lane (1: %lld, 2: %lld, 3: %lld, 4: %lld), "
+                "%.1f (neighbour, element) units per element\n", (long long)lanes, lanes ? (double)nbsum / lanes : 0.0,
+                (long long)hist[1], (long long)hist[2], (long long)hist[3], (long long)hist[4], (double)work / (double)nel);
+      }
     }
   }
   // ---- element-matrix kernel (Quad4, Triangle3/Gauss1): one tile set sized for the element-matrix slots of
@@ -1125,6 +1142,9 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   if (c->rows_path && !(a->flags & FA_FORCE_GENERIC))
     path = (a->flags & FA_DETERMINISTIC) ? fa::PATH_ROWS_ORDERED : (c->patch_path ? fa::PATH_PATCH : (c->pair_path ? fa::PATH_ROWS_PAIR : fa::PATH_ROWS));
   if (c->tile_path && (want_K || c->tile_force_only) && !(a->flags & (FA_FORCE_GENERIC | FA_DETERMINISTIC))) path = fa::PATH_TILES;
+  // 3-D elastic tiles: f_int from the pair lanes (atomic adds to f) when K is assembled and no strain cache is asked for
+  P.tile_fu = (path == fa::PATH_TILES && c->P.tile_fu && want_K && !(a->flags & FA_STORE_STRAIN)) ? 1 : 0;
+  if (P.tile_fu && P.overwrite && c->nel > 0) HIP_TRY(hipMemsetAsync(a->f_int, 0, sizeof(double) * c->ndof, st));
   if (emat) {                                          // element-matrix kernel: no atomics, so it also serves FA_DETERMINISTIC
     path = (emat == &c->fvec) ? fa::PATH_FVEC : fa::PATH_EMAT;
     P.eslot = emat->eslot; P.nval = emat->nval; P.fvec_val = emat->lpe;

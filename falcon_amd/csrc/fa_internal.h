@@ -75,6 +75,12 @@ constexpr int tile_rec_doubles(int rank, int fam, bool keep, int npe = 0) {
   const int S = (rank == 2) ? 3 : 6;
   return (tile_grad_records(rank, npe) ? npe * rank : rank * rank) + 1 + (fam == FAM_PF_MIEHE ? S * (S + 1) / 2 : (fam != FAM_LE ? 3 : 0)) + (fam != FAM_LE ? 1 : 0) + (keep ? S + 2 : 0);
 }
+// Grouped pair lanes (TileOpts::group, fa_tile_impl.h): neighbours per lane for the 3-D elastic kernels (Hex20 / Hex8 with
+// Hooke), 1 = off.  Host and kernel must agree: the lane records differ.
+#ifndef FA_TILE_GROUP
+#define FA_TILE_GROUP 4
+#endif
+constexpr int tile_group(int rank, int fam) { return (rank == 3 && fam == FAM_LE) ? FA_TILE_GROUP : 1; }
 // doubles of one element slot (nip records): odd, so that lanes reading the same field of different slots spread
 // over the LDS banks
 constexpr int tile_slot_doubles(int nip, int rec_doubles) { return (nip * rec_doubles) | 1; }
@@ -155,7 +161,7 @@ struct Params {
   double*        f;
   // ---- sizes / switches ----
   int64_t nnode, nel;
-  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2, ntile3, tile_lds, tile_stage, tile_block, tile_sym, tile_split, rec_padded, emat_lpe, fvec_val, conn_stride, st_maxn, st_maxe, persistent;
+  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2, ntile3, tile_lds, tile_stage, tile_block, tile_sym, tile_split, tile_fu, rec_padded, emat_lpe, fvec_val, conn_stride, st_maxn, st_maxe, persistent;
   int32_t cnt[4];            // entries per neighbour node in a row of dof type i
   int32_t off[4][4];         // offset of column type j inside that group, -1 if not in the pattern
   // ---- constants ----

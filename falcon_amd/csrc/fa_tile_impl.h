@@ -95,6 +95,12 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   for (int i = tid; i < n_el * NPE; i += BLK) sConn[i] = P.tconn[(int64_t)elem_off * NPE + i];
   __syncthreads();
 
+  // Hooke with grouped pair lanes, GET_MATRIX0 passes without a strain cache: f_int = sum_b K_ab u_b is formed by the pair
+  // lanes from the blocks they hold anyway (the elastic f_int IS K u: sigma = D B u), so the Gauss-point lanes skip
+  // strain, stress and the f rows -- most of their work.  All f updates are then atomic adds to global memory (blocks
+  // written for a neighbour tile's node add to that node's row); the host zeroes f first in overwrite mode.
+  constexpr bool FU_CAP = WANT_K && !PF && tile_group(RANK, FAM) > 1 && !TR::GREC;
+  const bool fu = FU_CAP && P.tile_fu != 0;
   // ---- phase 1: Gauss points ----
   double err_acc = 0.0;
   for (int t = tid; t < n_el * NIP; t += BLK) {
@@ -141,6 +147,17 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
       inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
     }
     const double w = tabW[ip] * det;
+    if constexpr (FU_CAP) {
+      if (fu) {                                        // f_int comes from the pair lanes (K u): the point only leaves J^-1 and w det J
+        double* rec = sRec + s * SLOTW + ip * RW;
+#pragma unroll
+        for (int k = 0; k < RANK; k++)
+#pragma unroll
+          for (int i = 0; i < RANK; i++) rec[TR::O_INV + k * RANK + i] = inv[k][i];
+        rec[TR::O_W] = w;
+        continue;
+      }
+    }
     double eps[S], pf = 0.0, pf0 = 0.0, pfX = 0.0, gphi[RANK];
 #pragma unroll
     for (int c = 0; c < S; c++) eps[c] = 0.0;
@@ -250,11 +267,12 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   __syncthreads();
 
   // ---- f_int rows of the owned nodes ----
-  for (int i = tid; i < n_own * NDOF; i += BLK) {
-    const int ia = i / NDOF;
-    const int64_t q = (int64_t)P.tnodes[node_off + ia] * NDOF + (i - ia * NDOF);
-    P.f[q] = P.overwrite ? sF[i] : P.f[q] + sF[i];
-  }
+  if (!fu)
+    for (int i = tid; i < n_own * NDOF; i += BLK) {
+      const int ia = i / NDOF;
+      const int64_t q = (int64_t)P.tnodes[node_off + ia] * NDOF + (i - ia * NDOF);
+      P.f[q] = P.overwrite ? sF[i] : P.f[q] + sF[i];
+    }
 
   // ---- phase 2: node-pair blocks of K1..K4 (PhaseFractureModel.cpp:713-722) ----
   if constexpr (WANT_K) {
@@ -271,6 +289,139 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   const int lane = tid & 63;
   const uint4* __restrict__ prec = reinterpret_cast<const uint4*>(P.tpairs) + pair_off;
   uint4 pw_next = (tid < n_pairs) ? prec[tid] : make_uint4(0u, 0u, 0u, 0u);
+  constexpr int GRP = tile_group(RANK, FAM);
+  if constexpr (GRP > 1) {
+    // ---- grouped pair lanes (TileOpts::group): one lane serves up to 4 neighbours b of its node a that share the same
+    //      elements with a.  Per element and point: the record and grad N_a once, then per neighbour 3 table reads and
+    //      18 multiply-adds (g_b and M_b += w g_a g_b^T).  Hooke only: K1 follows from M after the loops. ----
+    static_assert(!PF && RANK == 3 && GRP <= 4, "grouped lanes: 3-D elastic kernels");
+    for (int p0 = 0; p0 < n_pairs; p0 += BLK) {
+      const int p = p0 + tid;
+      const bool active = p < n_pairs;
+      const uint4 pw = pw_next;
+      pw_next = (p + BLK < n_pairs) ? prec[p + BLK] : make_uint4(0u, 0u, 0u, 0u);
+      const int ia = (int)(pw.x & 0xFFFFu), nb = (int)((pw.x >> 16) & 0xFFu), cnt = (int)(pw.x >> 24);
+      const uint32_t* __restrict__ ents = P.tents + (int64_t)ent_off + pw.y;
+      uint32_t bw[GRP];
+#pragma unroll
+      for (int j = 0; j < GRP; j++) bw[j] = (j < nb) ? ents[j] : 0u;
+      double M[GRP][3][3];
+#pragma unroll
+      for (int j = 0; j < GRP; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) M[j][i][k] = 0.0;
+      uint32_t e0_next = pw.w, e1_next = cnt > 0 ? ents[nb + 1] : 0u;
+#pragma unroll 1
+      for (int t = 0; t < cnt; t++) {
+        const uint32_t e0 = e0_next, e1 = e1_next;
+        if (t + 1 < cnt) { e0_next = ents[nb + 2 * t + 2]; e1_next = ents[nb + 2 * t + 3]; }
+        const int slot = (int)(e0 & 0xFFFFu), la = (int)((e0 >> 16) & 0xFFu);
+#pragma unroll 1
+        for (int ip = 0; ip < NIP; ip++) {
+          const double* rec = sRec + slot * SLOTW + ip * RW;
+          double inv[3][3];
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) inv[k][i] = rec[TR::O_INV + k * 3 + i];
+          const double w = rec[TR::O_W];
+          double wga[3];
+          {
+            const double* da = tabD + (ip * NPE + la) * 3;
+            const double d0 = da[0], d1 = da[1], d2 = da[2];
+#pragma unroll
+            for (int i = 0; i < 3; i++) wga[i] = w * (d0 * inv[0][i] + d1 * inv[1][i] + d2 * inv[2][i]);
+          }
+#pragma unroll
+          for (int j = 0; j < GRP; j++) {
+            if (j < nb) {
+              const int lb = (int)((e1 >> (8 * j)) & 0xFFu);
+              const double* db = tabD + (ip * NPE + lb) * 3;
+              const double d0 = db[0], d1 = db[1], d2 = db[2];
+#pragma unroll
+              for (int k = 0; k < 3; k++) {
+                const double gbk = d0 * inv[0][k] + d1 * inv[1][k] + d2 * inv[2][k];
+#pragma unroll
+                for (int i = 0; i < 3; i++) M[j][i][k] += wga[i] * gbk;
+              }
+            }
+          }
+        }
+      }
+      const int lg = (int)((pw.z >> 24) & 3u);
+      if (__any(lg != 0)) {
+        auto dpp = [](double v, auto ctl) {
+          int lo = __double2loint(v), hi = __double2hiint(v);
+          lo = __builtin_amdgcn_mov_dpp(lo, decltype(ctl)::value, 0xF, 0xF, true);
+          hi = __builtin_amdgcn_mov_dpp(hi, decltype(ctl)::value, 0xF, 0xF, true);
+          return __hiloint2double(hi, lo);
+        };
+#pragma unroll
+        for (int j = 0; j < GRP; j++)
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              double& v = M[j][i][k];
+              const double p1 = dpp(v, std::integral_constant<int, 0xB1>());
+              v += (lg >= 1) ? p1 : 0.0;
+              const double p2 = dpp(v, std::integral_constant<int, 0x4E>());
+              v += (lg >= 2) ? p2 : 0.0;
+            }
+      }
+      if (!active || ((pw.z >> 26) & 3u) != 0) continue;
+      const bool diag = (pw.z >> 30) & 1u;
+#pragma unroll
+      for (int j = 0; j < GRP; j++) {
+        if (j >= nb) continue;
+        const double tr = M[j][0][0] + M[j][1][1] + M[j][2][2];
+        const int ib = (int)(bw[j] & 0xFFFFu), kpos2 = (int)((bw[j] >> 16) & 0xFFu), kpos = (int)(bw[j] >> 24);
+        // canonical blocked layout, 3 dofs per node: row i of node io starts at sRow[io] + i * 3 * deg
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          double row[3], col[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            row[k] = (i == k) ? (P.hd0 - P.hd3) * M[j][i][i] + P.hd3 * tr : P.hd1 * M[j][i][k] + P.hd3 * M[j][k][i];   // K_ab[i][k]
+            col[k] = (i == k) ? row[k] : P.hd1 * M[j][k][i] + P.hd3 * M[j][i][k];                                        // K_ba[i][k] = K_ab[k][i]
+          }
+          {
+            const long long b = sRow[ia] + (long long)i * 3 * sDeg[ia] + (long long)kpos * 3;
+#pragma unroll
+            for (int k = 0; k < 3; k++) P.K[b + k] = P.overwrite ? row[k] : P.K[b + k] + row[k];
+          }
+          if (!diag) {
+            const long long b = sRow[ib] + (long long)i * 3 * sDeg[ib] + (long long)kpos2 * 3;
+#pragma unroll
+            for (int k = 0; k < 3; k++) P.K[b + k] = P.overwrite ? col[k] : P.K[b + k] + col[k];
+          }
+          if constexpr (FU_CAP) {
+            if (fu) {                                  // f_a += K_ab u_b, f_b += K_ba u_a
+              const double* ub = sNod + (diag ? ia : ib) * NODW + RANK;
+              const double* ua = sNod + ia * NODW + RANK;
+              atomicAdd(&sF[ia * NDOF + i], row[0] * ub[0] + row[1] * ub[1] + row[2] * ub[2]);
+              if (!diag) {
+                const double v = col[0] * ua[0] + col[1] * ua[1] + col[2] * ua[2];
+                if (ib < n_own) atomicAdd(&sF[ib * NDOF + i], v);
+                else atomicAdd(&P.f[(int64_t)P.tnodes[node_off + ib] * NDOF + i], v);
+              }
+            }
+          }
+        }
+      }
+    }
+    if constexpr (FU_CAP) {
+      if (fu) {
+        __syncthreads();
+        for (int i = tid; i < n_own * NDOF; i += BLK) {
+          const int io = i / NDOF;
+          atomicAdd(&P.f[(int64_t)P.tnodes[node_off + io] * NDOF + (i - io * NDOF)], sF[i]);
+        }
+      }
+    }
+  } else
   for (int p0 = 0; p0 < n_pairs; p0 += BLK) {           // uniform trip count: every lane of a wave takes part in the write-out
     const int p = p0 + tid;
     const bool active = p < n_pairs;

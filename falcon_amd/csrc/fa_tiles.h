@@ -51,6 +51,15 @@ struct TileOpts {
                             // operations before the first of them writes: the lanes of a wave then do (nearly) equal
                             // work instead of 8 / 4 / 2 / 1 elements.  Pair word 2: bits 24-25 log2(lanes of the
                             // group), bits 26-27 index of this lane in its group.
+  int group = 0;            // order 0 with sym_all, > 1: GROUPED pair lanes.  The neighbours b of an owned node a that share
+                            // exactly the same elements with a (e.g. the 4 nodes of a Hex20 that lie on no face through
+                            // its corner a) go to one lane, up to `group` of them: the lane reads a Gauss-point record and
+                            // the gradient of a once per point and serves all its b with them.  Lane record (4 words):
+                            //   ia | nb << 16 | elements << 24;  entry offset;  flags (bits 24-27 as with `split`, bit 30
+                            //   diagonal);  first element word
+                            // entries of a lane: nb words  ib | position of a in b's row << 16 | position of b in a's row
+                            // << 24, then per element 2 words  slot | la << 16  and  lb_0 | lb_1 << 8 | lb_2 << 16 | lb_3 << 24
+  bool write_order = false; // grouped lanes of equal work sorted by (node, position in its row) instead of by first element
   int fvec = 0;             // > 0: force-vector mode (fa_emat_impl.h, assemble_fvec): no element slots, no pair lanes; per
                             // element the slot ranks of its nodes, per owned node its valence (<= fvec)
 };

@@ -196,10 +196,13 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
     const int32_t* c = counts.data() + t * 5;
     T.max_own = std::max(T.max_own, c[0]); T.max_all = std::max(T.max_all, c[1]); T.max_el = std::max(T.max_el, c[2]);
   }
-  const bool split_mode = opts.split > 0 && order_mode == 0;
+  const bool group_mode = opts.group > 1 && order_mode == 0 && opts.sym_all;
+  std::vector<std::vector<uint32_t>> group_ents;       // group mode: the entry words of a tile are counted as they are made
+  if (group_mode) group_ents.resize((size_t)ntile);
+  const bool split_mode = (opts.split > 0 && order_mode == 0) || group_mode;
   std::vector<std::vector<uint32_t>> split_pairs;      // split mode: the lane count of a tile is known only after its pairs are cut
   if (split_mode) split_pairs.resize((size_t)ntile); else T.tpairs.assign((size_t)o_pair[ntile] * 4, 0);
-  T.tents.assign((size_t)o_ent[ntile], 0);
+  if (!(opts.group > 1 && order_mode == 0 && opts.sym_all)) T.tents.assign((size_t)o_ent[ntile], 0);
   T.point_redundancy = (double)o_el[ntile] / (double)nel;
   if (opts.fvec > 0) { T.eslot.assign((size_t)o_el[ntile], 0); T.nval.assign((size_t)o_node[ntile], 0); }
 
@@ -320,8 +323,86 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
           return (ent[x.first] & 0xFFFFu) < (ent[y.first] & 0xFFFFu);
         });
       }
-      uint32_t* tq = T.tents.data() + o_ent[t];
+      uint32_t* tq = group_mode ? nullptr : T.tents.data() + o_ent[t];
       uint32_t run = 0;
+      if (group_mode) {
+        // pairs of one owned node with identical element lists -> groups of up to opts.group neighbours
+        const uint32_t split = opts.split > 0 ? (uint32_t)opts.split : 0xFFFFu;
+        auto lanes_of = [&](uint32_t cnt) { return cnt > 2u * split ? 4u : (cnt > split ? 2u : 1u); };
+        struct Grp { uint32_t ia, cnt, nb; uint32_t pi[4]; bool diag; };
+        std::vector<Grp> gs;
+        {
+          std::vector<size_t> idx(pt.size());
+          for (size_t i = 0; i < pt.size(); i++) idx[i] = i;
+          auto same_list = [&](const PairTmp& x, const PairTmp& y) {
+            if (x.cnt != y.cnt) return false;
+            for (uint32_t k = 0; k < x.cnt; k++) if ((ent[x.first + k] & 0xFFFFu) != (ent[y.first + k] & 0xFFFFu)) return false;
+            return true;
+          };
+          auto list_less = [&](size_t xi, size_t yi) {
+            const PairTmp &x = pt[xi], &y = pt[yi];
+            const uint32_t ax = x.w0 & 0xFFFFu, ay = y.w0 & 0xFFFFu;
+            if (ax != ay) return ax < ay;
+            if (x.diag != y.diag) return x.diag;
+            if (x.cnt != y.cnt) return x.cnt > y.cnt;
+            for (uint32_t k = 0; k < x.cnt; k++) {
+              const uint32_t sx = ent[x.first + k] & 0xFFFFu, sy = ent[y.first + k] & 0xFFFFu;
+              if (sx != sy) return sx < sy;
+            }
+            return xi < yi;
+          };
+          std::sort(idx.begin(), idx.end(), list_less);
+          for (size_t q = 0; q < idx.size(); q++) {
+            const PairTmp& x = pt[idx[q]];
+            const uint32_t ia = x.w0 & 0xFFFFu;
+            if (!gs.empty() && !x.diag && !gs.back().diag && gs.back().ia == ia && gs.back().nb < (uint32_t)std::min(opts.group, 4) &&
+                same_list(pt[gs.back().pi[0]], x)) { gs.back().pi[gs.back().nb++] = (uint32_t)idx[q]; continue; }
+            Grp g; g.ia = ia; g.cnt = x.cnt; g.nb = 1; g.pi[0] = (uint32_t)idx[q]; g.pi[1] = g.pi[2] = g.pi[3] = 0; g.diag = x.diag;
+            gs.push_back(g);
+          }
+        }
+        // lane order: groups of 4 / 2 / 1 lanes, then by neighbours per lane, by elements per lane, by first element
+        std::stable_sort(gs.begin(), gs.end(), [&](const Grp& x, const Grp& y) {
+          const uint32_t gx = lanes_of(x.cnt), gy = lanes_of(y.cnt);
+          if (gx != gy) return gx > gy;
+          if (x.nb != y.nb) return x.nb > y.nb;
+          const uint32_t px = (x.cnt + gx - 1) / gx, py = (y.cnt + gy - 1) / gy;
+          if (px != py) return px > py;
+          if (x.cnt == 0 || y.cnt == 0) return false;
+          if (opts.write_order) {                        // neighbouring lanes write neighbouring chunks of the same rows
+            if (x.ia != y.ia) return x.ia < y.ia;
+            return ((pt[x.pi[0]].w0 >> 16) & 0xFFu) < ((pt[y.pi[0]].w0 >> 16) & 0xFFu);
+          }
+          return (ent[pt[x.pi[0]].first] & 0xFFFFu) < (ent[pt[y.pi[0]].first] & 0xFFFFu);
+        });
+        std::vector<uint32_t>& tp = split_pairs[(size_t)t];
+        std::vector<uint32_t>& te = group_ents[(size_t)t];
+        tp.clear(); te.clear();
+        for (const Grp& g : gs) {
+          const uint32_t gl = lanes_of(g.cnt), lg = gl == 4 ? 2u : (gl == 2 ? 1u : 0u), per = (g.cnt + gl - 1) / gl;
+          for (uint32_t j = 0; j < gl; j++) {
+            const uint32_t b0 = std::min(g.cnt, j * per), b1 = std::min(g.cnt, (j + 1) * per), c = b1 - b0;
+            const uint32_t off = (uint32_t)te.size();
+            for (uint32_t m = 0; m < g.nb; m++) {        // ib | position of a in b's row << 16 | position of b in a's row << 24
+              const PairTmp& x = pt[g.pi[m]];
+              te.push_back((x.w2 & 0x00FFFFFFu) | (((x.w0 >> 16) & 0xFFu) << 24));
+            }
+            for (uint32_t k = b0; k < b1; k++) {
+              const uint32_t e0 = ent[pt[g.pi[0]].first + k];
+              uint32_t lbw = 0;
+              for (uint32_t m = 0; m < 4; m++) lbw |= (ent[pt[g.pi[m < g.nb ? m : 0]].first + k] >> 24) << (8 * m);
+              te.push_back(e0 & 0x00FFFFFFu);            // slot | la << 16
+              te.push_back(lbw);
+            }
+            tp.push_back(g.ia | (g.nb << 16) | (c << 24));
+            tp.push_back(off);
+            tp.push_back((g.diag ? 0x40000000u : 0u) | (lg << 24) | (j << 26));
+            tp.push_back(c ? (ent[pt[g.pi[0]].first + b0] & 0x00FFFFFFu) : 0u);
+          }
+        }
+        ti[6] = (int32_t)(tp.size() / 4);
+        continue;
+      }
       if (split_mode) {
         // groups of 4 / 2 / 1 lanes, largest groups first (a group never straddles a wave), then by elements per lane
         auto lanes_of = [&](uint32_t cnt) { return cnt > 2u * opts.split ? 4u : (cnt > (uint32_t)opts.split ? 2u : 1u); };
@@ -359,6 +440,21 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
       }
     }
   });
+  if (group_mode) {                                    // concatenate the tiles' entry words
+    int64_t total = 0;
+    for (int64_t t = 0; t < ntile; t++) {
+      T.tinfo[(size_t)t * kTileInfo + 7] = (int32_t)total;
+      total += (int64_t)group_ents[(size_t)t].size();
+      if (total > lim) return false;
+    }
+    T.tents.assign((size_t)std::max<int64_t>(total, 1), 0);
+    par_for(ntile, [&](int64_t tb, int64_t te) {
+      for (int64_t t = tb; t < te; t++) {
+        const std::vector<uint32_t>& v = group_ents[(size_t)t];
+        if (!v.empty()) std::memcpy(T.tents.data() + (size_t)T.tinfo[(size_t)t * kTileInfo + 7], v.data(), v.size() * 4);
+      }
+    });
+  }
   if (split_mode) {                                    // concatenate the tiles' lane records
     int64_t total = 0;
     for (int64_t t = 0; t < ntile; t++) {
