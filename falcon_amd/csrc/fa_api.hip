@@ -1186,8 +1186,8 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   }
 #ifdef FA_TRACE
   static void* dbgbuf = nullptr; static int ncall = 0;
-  const size_t dbgbytes = (size_t)std::max(c->ntile2, 1) * 4 * 8 * sizeof(long long);
-  if (!dbgbuf) HIP_TRY(hipMalloc(&dbgbuf, dbgbytes));
+  const size_t dbgbytes = (size_t)std::max(std::max(c->ntile2, c->ntile3), 1) * 4 * 8 * sizeof(long long);
+  if (!dbgbuf) { HIP_TRY(hipMalloc(&dbgbuf, dbgbytes)); HIP_TRY(hipMemset(dbgbuf, 0, dbgbytes)); }
   P.dbg = dbgbuf;
 #endif
   int rc = c->launch(P, c->fam, want_K, keep, path, grid, (void*)st);

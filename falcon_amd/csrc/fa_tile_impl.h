@@ -51,6 +51,9 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   __shared__ double sErr[BLK / 64];
 
   const int tid = threadIdx.x;
+#ifdef FA_TRACE
+  long long trc[6]; trc[0] = __builtin_readcyclecounter();
+#endif
   const int per = (int)gridDim.x >> 3;                 // XCD bands: neighbouring tiles share halo nodes in one L2
   const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
   if (tile >= P.ntile3) return;
@@ -64,7 +67,9 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   const bool ext_state = PF && (SP::model(P) == 2 || SP::model(P) == 3 || SP::model(P) >= 5);
   double* sF   = sExt + (ext_state ? 2 * n_all : 0);
   const int n_rows = P.tile_sym ? n_all : n_own;      // cross-tile mirror lanes also write rows of halo nodes
-  long long* sRow = reinterpret_cast<long long*>(sF + n_own * NDOF);   // first CSR entry of every (owned) node's first row
+  // grouped pair lanes (3-D elastic kernels): f image for every tile node -- the pair lanes add K_ba u_a for halo nodes b too
+  const int n_f = (tile_group(RANK, FAM) > 1) ? n_all : n_own;
+  long long* sRow = reinterpret_cast<long long*>(sF + n_f * NDOF);     // first CSR entry of every (owned) node's first row
   int* sDeg = reinterpret_cast<int*>(sRow + n_rows);                   // neighbours of every (owned) node
   double* sTab = reinterpret_cast<double*>(sRow + n_rows) + (n_rows + 1) / 2;
   uint16_t* sConn = (uint16_t*)(sTab + TABN);
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
       else if (SP::model(P) >= 5) { sExt[2 * i] = 0.0; sExt[2 * i + 1] = P.stateX[dp]; }
     }
   }
-  for (int i = tid; i < n_own * NDOF; i += BLK) sF[i] = 0.0;
+  for (int i = tid; i < n_f * NDOF; i += BLK) sF[i] = 0.0;
   for (int i = tid; i < n_rows; i += BLK) {
     const int64_t r0 = (int64_t)P.tnodes[node_off + i] * NDOF;
     const long long b0 = P.row_ptr[r0], b1 = P.row_ptr[r0 + 1];
@@ -94,6 +99,9 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   for (int i = tid; i < TABN; i += BLK) sTab[i] = P.tab[i];
   for (int i = tid; i < n_el * NPE; i += BLK) sConn[i] = P.tconn[(int64_t)elem_off * NPE + i];
   __syncthreads();
+#ifdef FA_TRACE
+  trc[1] = __builtin_readcyclecounter();
+#endif
 
   // Hooke with grouped pair lanes, GET_MATRIX0 passes without a strain cache: f_int = sum_b K_ab u_b is formed by the pair
   // lanes from the blocks they hold anyway (the elastic f_int IS K u: sigma = D B u), so the Gauss-point lanes skip
@@ -266,6 +274,9 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   }
   __syncthreads();
 
+#ifdef FA_TRACE
+  trc[2] = __builtin_readcyclecounter();
+#endif
   // ---- f_int rows of the owned nodes ----
   if (!fu)
     for (int i = tid; i < n_own * NDOF; i += BLK) {
@@ -387,6 +398,9 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
             row[k] = (i == k) ? (P.hd0 - P.hd3) * M[j][i][i] + P.hd3 * tr : P.hd1 * M[j][i][k] + P.hd3 * M[j][k][i];   // K_ab[i][k]
             col[k] = (i == k) ? row[k] : P.hd1 * M[j][k][i] + P.hd3 * M[j][i][k];                                        // K_ba[i][k] = K_ab[k][i]
           }
+#ifdef FA_TILE_NOWRITE                                   // ablation build: no K stores (the blocks stay live through a never-true test)
+          if (row[0] + row[1] + row[2] + col[0] + col[1] + col[2] == 1.2345e300) P.K[0] = 1.0;
+#else
           {
             const long long b = sRow[ia] + (long long)i * 3 * sDeg[ia] + (long long)kpos * 3;
 #pragma unroll
@@ -397,6 +411,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
 #pragma unroll
             for (int k = 0; k < 3; k++) P.K[b + k] = P.overwrite ? col[k] : P.K[b + k] + col[k];
           }
+#endif
           if constexpr (FU_CAP) {
             if (fu) {                                  // f_a += K_ab u_b, f_b += K_ba u_a
               const double* ub = sNod + (diag ? ia : ib) * NODW + RANK;
@@ -404,8 +419,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
               atomicAdd(&sF[ia * NDOF + i], row[0] * ub[0] + row[1] * ub[1] + row[2] * ub[2]);
               if (!diag) {
                 const double v = col[0] * ua[0] + col[1] * ua[1] + col[2] * ua[2];
-                if (ib < n_own) atomicAdd(&sF[ib * NDOF + i], v);
-                else atomicAdd(&P.f[(int64_t)P.tnodes[node_off + ib] * NDOF + i], v);
+                atomicAdd(&sF[ib * NDOF + i], v);        // owned or halo: the image covers every tile node
               }
             }
           }
@@ -415,9 +429,10 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
     if constexpr (FU_CAP) {
       if (fu) {
         __syncthreads();
-        for (int i = tid; i < n_own * NDOF; i += BLK) {
+        for (int i = tid; i < n_all * NDOF; i += BLK) {
           const int io = i / NDOF;
-          atomicAdd(&P.f[(int64_t)P.tnodes[node_off + io] * NDOF + (i - io * NDOF)], sF[i]);
+          const double v = sF[i];
+          if (v != 0.0) atomicAdd(&P.f[(int64_t)P.tnodes[node_off + io] * NDOF + (i - io * NDOF)], v);
         }
       }
     }
@@ -695,6 +710,16 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
     }
   }
   }
+#ifdef FA_TRACE
+  trc[3] = __builtin_readcyclecounter();
+  __builtin_amdgcn_s_waitcnt(0);
+  trc[4] = __builtin_readcyclecounter();
+  if ((tid & 63) == 0 && (tid >> 6) < 4 && P.dbg != nullptr) {
+    long long* out = (long long*)P.dbg + ((int64_t)tile * 4 + (tid >> 6)) * 8;
+    for (int q = 0; q < 5; q++) out[q] = trc[q];
+    out[5] = n_pairs; out[6] = n_el; out[7] = n_all;
+  }
+#endif
   if (PF && P.err_part != nullptr) reduce_err<BLK>(err_acc, sErr, &P.err_part[tile]);
 }
 

@@ -54,7 +54,7 @@ struct Cutter {                                        // greedy cut of the sort
 
   int64_t bytes(int64_t n_el, int64_t n_all, int64_t n_own) const {
     const int64_t slot = opts.fvec > 0 ? 0 : (opts.slot_doubles > 0 ? opts.slot_doubles : tile_slot_doubles(nip, rec_doubles));
-    return 8 * (n_el * slot + n_all * node_doubles + n_own * (opts.own_doubles + (opts.no_f_image ? 0 : ndofpn) + 2) + (opts.sym_all ? 2 * (n_all - n_own) : 0) + (opts.no_tab ? 0 : tabn)) + 2 * n_el * (opts.conn_pad4 ? 4 : npe) + 16 + extra_bytes;
+    return 8 * (n_el * slot + n_all * node_doubles + n_own * (opts.own_doubles + (opts.no_f_image ? 0 : ndofpn) + 2) + (opts.sym_all ? 2 * (n_all - n_own) : 0) + (opts.group > 1 ? ndofpn * (n_all - n_own) : 0) + (opts.no_tab ? 0 : tabn)) + 2 * n_el * (opts.conn_pad4 ? 4 : npe) + 16 + extra_bytes;
   }
   // Tiles end where the Morton cell of 2^L codes ends (once half full) or where the LDS budget / counters say so.
   // Returns false if one node alone does not fit.  starts: first position of every tile in `order` (+ sentinel).
