@@ -835,7 +835,6 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       topt.split = row_order ? 0 : (dbg.tile_split >= 0 ? dbg.tile_split : 2);
       // grouped pair lanes: the kernel's record format is fixed at compile time, so the tiling must follow it
       topt.group = fa::tile_group(rank, c->fam);
-      topt.write_order = getenv("FA_TILE_WORDER") != nullptr && atoi(getenv("FA_TILE_WORDER")) != 0;
       P.tile_fu = (topt.group > 1 && (dbg.tile_fu >= 0 ? dbg.tile_fu != 0 : true)) ? 1 : 0;   // capability; decided per call
       if (topt.group > 1 && !topt.sym_all) return fail(FA_ERR_UNSUPPORTED, "FA_TILE_SYM=0 / row order is not available for the grouped pair lanes of the 3-D elastic kernels");
       P.tile_split = topt.split > 0 ? 1 : 0;

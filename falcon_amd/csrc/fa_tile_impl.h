@@ -401,16 +401,17 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
 #ifdef FA_TILE_NOWRITE                                   // ablation build: no K stores (the blocks stay live through a never-true test)
           if (row[0] + row[1] + row[2] + col[0] + col[1] + col[2] == 1.2345e300) P.K[0] = 1.0;
 #else
-          {
-            const long long b = sRow[ia] + (long long)i * 3 * sDeg[ia] + (long long)kpos * 3;
-#pragma unroll
-            for (int k = 0; k < 3; k++) P.K[b + k] = P.overwrite ? row[k] : P.K[b + k] + row[k];
-          }
-          if (!diag) {
-            const long long b = sRow[ib] + (long long)i * 3 * sDeg[ib] + (long long)kpos2 * 3;
-#pragma unroll
-            for (int k = 0; k < 3; k++) P.K[b + k] = P.overwrite ? col[k] : P.K[b + k] + col[k];
-          }
+          // a 24-byte row chunk as one 16-byte and one 8-byte store (the address is 8-byte aligned only; global memory
+          // takes unaligned vector stores)
+          auto put3 = [&](long long b, const double (&v)[3]) {
+            typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+            double* q = P.K + b;
+            if (P.overwrite) { d2u t; t.x = v[0]; t.y = v[1]; *reinterpret_cast<d2u*>(q) = t; q[2] = v[2]; }
+            else { const d2u o = *reinterpret_cast<const d2u*>(q); d2u t; t.x = o.x + v[0]; t.y = o.y + v[1]; const double o2 = q[2];
+                   *reinterpret_cast<d2u*>(q) = t; q[2] = o2 + v[2]; }
+          };
+          put3(sRow[ia] + (long long)i * 3 * sDeg[ia] + (long long)kpos * 3, row);
+          if (!diag) put3(sRow[ib] + (long long)i * 3 * sDeg[ib] + (long long)kpos2 * 3, col);
 #endif
           if constexpr (FU_CAP) {
             if (fu) {                                  // f_a += K_ab u_b, f_b += K_ba u_a

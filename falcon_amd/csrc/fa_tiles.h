@@ -59,7 +59,6 @@ struct TileOpts {
                             //   diagonal);  first element word
                             // entries of a lane: nb words  ib | position of a in b's row << 16 | position of b in a's row
                             // << 24, then per element 2 words  slot | la << 16  and  lb_0 | lb_1 << 8 | lb_2 << 16 | lb_3 << 24
-  bool write_order = false; // grouped lanes of equal work sorted by (node, position in its row) instead of by first element
   int fvec = 0;             // > 0: force-vector mode (fa_emat_impl.h, assemble_fvec): no element slots, no pair lanes; per
                             // element the slot ranks of its nodes, per owned node its valence (<= fvec)
 };

@@ -369,10 +369,6 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
           const uint32_t px = (x.cnt + gx - 1) / gx, py = (y.cnt + gy - 1) / gy;
           if (px != py) return px > py;
           if (x.cnt == 0 || y.cnt == 0) return false;
-          if (opts.write_order) {                        // neighbouring lanes write neighbouring chunks of the same rows
-            if (x.ia != y.ia) return x.ia < y.ia;
-            return ((pt[x.pi[0]].w0 >> 16) & 0xFFu) < ((pt[y.pi[0]].w0 >> 16) & 0xFFu);
-          }
           return (ent[pt[x.pi[0]].first] & 0xFFFFu) < (ent[pt[y.pi[0]].first] & 0xFFFFu);
         });
         std::vector<uint32_t>& tp = split_pairs[(size_t)t];
