@@ -533,6 +533,21 @@ def test_non_default_kernel_paths(shape, model, material, keep, monkeypatch):
     run_both(shape, model, material, keep=keep, want_K=False)
 
 
+@pytest.mark.parametrize("shape,model,material", [
+    (capi.QUAD4_G2, capi.PHASE_FRACTURE, capi.AMOR_PHASE),
+    (capi.QUAD4_G2, capi.LINEAR_ELASTICITY, capi.HOOKE),
+    (capi.TRI3_G1, capi.MICRO_PHASE_FRACTURE, capi.BOURDIN_PHASE)])
+def test_persistent_force_vector_kernel(shape, model, material, monkeypatch):
+    """FA_PERSIST=1 (opt-in): the persistent LDS-DMA form of the force-vector kernel; FA_FVEC=0: the row kernel's
+    GET_INT_VECTOR pass that it replaced."""
+    monkeypatch.setenv("FA_PERSIST", "1")
+    run_both(shape, model, material, want_K=False)
+    run_both(shape, model, material, want_K=False, flags=capi.ACCUMULATE, shuffle=True)
+    monkeypatch.delenv("FA_PERSIST")
+    monkeypatch.setenv("FA_FVEC", "0")
+    run_both(shape, model, material, want_K=False)
+
+
 def test_cooperative_kernel_on_a_callers_pattern():
     """Quad8 with a caller-supplied (reversed-row) pattern: the cooperative kernel with per-entry column search."""
     shape, model, material = capi.QUAD8_G3, capi.PHASE_FRACTURE, capi.AMOR_PHASE

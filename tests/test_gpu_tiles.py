@@ -80,6 +80,8 @@ def test_tile_kernel_parity_on_many_tiles(case):
     asm.assemble(t(st), None, f4, flags=capi.OVERWRITE, **args)
     torch.cuda.synchronize()
     kmax = K.abs().max().item(); fmax = f.abs().max().item()
+    # without a strain cache the 3-D elastic kernels take f_int from the pair blocks (K u) instead of the Gauss points
+    assert (f2 - f).abs().max().item() < 1e-12 * fmax
     assert (K3 - 2.0 - K).abs().max().item() < 1e-12 * kmax and (f3 - 1.0 - f).abs().max().item() < 1e-12 * fmax
     assert (f4 - f).abs().max().item() < 1e-12 * fmax
 
