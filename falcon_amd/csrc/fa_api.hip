@@ -1376,7 +1376,8 @@ extern "C"// getArcFunc_ (PhaseFractureModel.cpp:844-1063)
 extern "C" fa_status fa_arc_func(fa_ctx* c, const double* state, const double* state0, double* jac10, double* fe_dissipation,
                                  void* stream) {
   if (!c || !state || !state0 || !jac10 || !fe_dissipation) return fail(FA_ERR_ARG, "null argument");
-  if (c->prob.model != FA_PHASE_FRACTURE) return fail(FA_ERR_UNSUPPORTED, "fa_arc_func: getArcFunc_ is provided for PhaseFracture only");
+  if (c->prob.model != FA_PHASE_FRACTURE && c->prob.model != FA_MICRO_PHASE_FRACTURE)
+    return fail(FA_ERR_UNSUPPORTED, "fa_arc_func: getArcFunc_ is provided for PhaseFracture and MicroPhaseFracture only");
   FA_ON_DEVICE(c->prob.device);
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (int)((c->nnode + 127) / 128);

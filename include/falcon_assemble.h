@@ -198,7 +198,8 @@ fa_status fa_output_data(fa_ctx* ctx, int32_t ncols, const int32_t* cols, double
  * arc-length solver, TSArclenModule.cpp:612-641): the same Gauss-point loop as getMatrix_ with other outputs --
  *     jac10 (device, ndof doubles; zeroed and filled, :870,:1055-1056) = d(dissipation)/d(state)
  *     fe_dissipation (device, 1 double) = sum wip (g(phi0) - g(phi)) Psi        (XProps::FE_DISSIPATION, :1046,:1059)
- * jac11 is 0 (:871).  state / state0: StateVector::get / getOld (:860-861), device.  PhaseFracture only.  One lane per
+ * jac11 is 0 (:871).  state / state0: StateVector::get / getOld (:860-861), device.  PhaseFracture and MicroPhaseFracture
+ * (MicroPhaseFractureModel.cpp:945-1166 is the same loop line for line: nodal phase field in the degradation).  One lane per
  * node over its elements, no atomics; bitwise repeatable. */
 fa_status fa_arc_func(fa_ctx* ctx, const double* state, const double* state0, double* jac10, double* fe_dissipation,
                       void* stream);

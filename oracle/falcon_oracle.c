@@ -1242,7 +1242,9 @@ int fo_arc_func(const fo_config* cfg, int nnode, const double* coords, int64_t n
                 const double* state, const double* state0, double* jac10, double* fvalue_out) {
   shape_t sh;
   if (shape_init(&sh, cfg->shape)) return -1;
-  if (cfg->model != FO_PHASE_FRACTURE) FAIL("getArcFunc_ is restated for PhaseFractureModel only");
+  /* MicroPhaseFractureModel::getArcFunc_ (MicroPhaseFractureModel.cpp:945-1166) is the same loop, line for line */
+  if (cfg->model != FO_PHASE_FRACTURE && cfg->model != FO_MICRO_PHASE_FRACTURE)
+    FAIL("getArcFunc_ is restated for PhaseFractureModel and MicroPhaseFractureModel");
   const int rank = sh.rank, nodeCount = sh.npe, ipCount = sh.nip;
   const int strCount = STRAIN_COUNTS[rank];
   const int dispCount = nodeCount * rank, phiCount = nodeCount;

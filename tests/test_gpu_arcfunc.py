@@ -9,7 +9,10 @@ from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
 
+MICRO = 100   # marker: the micromorphic model (same getArcFunc_ loop, MicroPhaseFractureModel.cpp:945-1166)
 CASES = [
+    (capi.QUAD4_G2, lambda: meshgen.grid_quad4(11, 9), capi.MIEHE_PHASE + MICRO, capi.AT2, capi.PLANE_STRAIN),
+    (capi.HEX8_G2, lambda: meshgen.grid_hex8(4, 4, 3), capi.BOURDIN_PHASE + MICRO, capi.AT1, capi.PLANE_STRAIN),
     (capi.QUAD4_G2, lambda: meshgen.grid_quad4(23, 17), capi.AMOR_PHASE, capi.AT2, capi.PLANE_STRAIN),
     (capi.QUAD4_G2, lambda: meshgen.grid_quad4(12, 9), capi.BOURDIN_PHASE, capi.CZM_CORNELISSEN, capi.PLANE_STRESS),
     (capi.TRI3_G1, lambda: meshgen.grid_tri3(14, 11), capi.MIEHE_PHASE, capi.AT1, capi.PLANE_STRAIN),
@@ -23,13 +26,16 @@ CASES = [
 def test_arc_func_matches_oracle(case):
     import torch
     shape, mesh, material, frac, pstate = CASES[case]
+    model = capi.PHASE_FRACTURE
+    if material >= MICRO:
+        material -= MICRO; model = capi.MICRO_PHASE_FRACTURE
     coords, conn = mesh()
     coords = meshgen.distort(coords, conn, 0.05, 4)
     coords, conn, _ = meshgen.shuffle_nodes(coords, conn, 5)
     rank = coords.shape[1]
     nd = rank + 1
     kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2, sigma_t=2.0, frac_type=frac, state=pstate)
-    asm = capi.Assembler(shape, capi.PHASE_FRACTURE, material, coords, conn, **kw)
+    asm = capi.Assembler(shape, model, material, coords, conn, **kw)
     dev = torch.device("cuda", 0)
     st = meshgen.smooth_state(coords, nd, seed=2, amp=5e-3, noise=1e-4, l0=0.3)
     st[rank::nd] = np.clip(st[rank::nd], 0.0, 0.8)        # pow(1 - phi, 2.5) of the CZM laws needs phi <= 1 at the Gauss points (quadratic shapes overshoot)
@@ -40,7 +46,7 @@ def test_arc_func_matches_oracle(case):
     jac2 = torch.empty_like(jac)
     fv2 = asm.arc_func(torch.from_numpy(st).to(dev), torch.from_numpy(st0).to(dev), jac2)
     torch.cuda.synchronize()
-    cfg = po.make_config(shape, capi.PHASE_FRACTURE, material, **kw)
+    cfg = po.make_config(shape, model, material, **kw)
     jref, fref = po.arc_func(cfg, coords, conn, st, st0)
     j = jac.cpu().numpy()
     for t in range(nd):
@@ -56,6 +62,6 @@ def test_arc_func_is_for_phase_fracture_only():
     coords, conn = meshgen.grid_quad4(4, 4)
     asm = capi.Assembler(capi.QUAD4_G2, capi.LINEAR_ELASTICITY, capi.HOOKE, coords, conn)
     v = torch.zeros(asm.ndof, dtype=torch.float64, device="cuda:0")
-    with pytest.raises(capi.FaError, match="PhaseFracture only"):
+    with pytest.raises(capi.FaError, match="MicroPhaseFracture only"):
         asm.arc_func(v, v, v.clone())
     asm.close()
