@@ -63,6 +63,7 @@ struct DebugOptions {
   int  emat = -1;         // FA_EMAT=0|1: element-matrix tile kernel (Quad4 / Triangle3) off / on
   int  fvec = -1;         // FA_FVEC=0|1: force-vector kernel (GET_INT_VECTOR passes of Quad4 / Triangle3) off / on
   int  persist = -1;      // FA_PERSIST=0|1: persistent LDS-DMA kernels off / on
+  int  fvec_atomic = -1;  // FA_FVEC_ATOMIC=0|1: force-vector kernel with ordered per-element rows | one atomic row per node
   int  fvec_blk = 0;      // FA_FVEC_BLK=192|256|320: its workgroup size = elements per tile (0: default)
   int  emat_lds = 0;      // FA_EMAT_LDS=n: LDS bytes of one element-matrix tile (0: default)
   int  emat_lpe = 0;      // FA_EMAT_LPE=1|2: lanes per element of its GET_MATRIX0 passes (0: default)
@@ -78,7 +79,7 @@ struct DebugOptions {
     auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_fu = geti("FA_TILE_FU", -1); o.tile_sort = geti("FA_TILE_SORT", -1); o.tile_split = geti("FA_TILE_SPLIT", -1);
     o.emat = geti("FA_EMAT", -1); o.emat_lds = geti("FA_EMAT_LDS", 0); o.emat_lpe = geti("FA_EMAT_LPE", 0);
-    o.emat_lpe_f = geti("FA_EMAT_LPE_F", 0); o.fvec = geti("FA_FVEC", -1); o.fvec_blk = geti("FA_FVEC_BLK", 0);
+    o.emat_lpe_f = geti("FA_EMAT_LPE_F", 0); o.fvec = geti("FA_FVEC", -1); o.fvec_blk = geti("FA_FVEC_BLK", 0); o.fvec_atomic = geti("FA_FVEC_ATOMIC", -1);
     o.persist = geti("FA_PERSIST", -1);
     o.no_pair = getenv("FA_NO_PAIR") != nullptr; o.pair_3d = getenv("FA_PAIR_3D") != nullptr;
     o.pad_rec = geti("FA_PAD_REC", 1); o.use_patch = getenv("FA_USE_PATCH") != nullptr;
@@ -338,6 +339,7 @@ fa_status resolve_scratch(int dev) {
 struct TileDev {
   bool ok = false;
   int ntile = 0, lds = 0, lpe = 1, block = 256;
+  int lds_alt = 0;                                              // force-vector tiles: LDS bytes with one f row per owned node (atomic form)
   int conn_stride = 0, maxn = 0, maxe = 0, plds = 0, pgrid = 0;   // persistent form: staging capacities, LDS bytes, grid
   bool persistent = false;
   double redundancy = 0.0;
@@ -904,13 +906,13 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       const int nodw = fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0);
       c->fvec.block = (dbg.fvec_blk == 128 || dbg.fvec_blk == 192 || dbg.fvec_blk == 256 || dbg.fvec_blk == 320) ? dbg.fvec_blk : 192;
       fa::TileOpts o;
-      o.no_tab = true; o.no_f_image = true; o.fvec = maxval; o.own_doubles = (maxval * nd) | 1; o.max_el = c->fvec.block;
+      o.no_tab = true; o.no_f_image = true; o.fvec = maxval; o.own_doubles = (maxval * nd) | 1; o.own_doubles_alt = nd; o.max_el = c->fvec.block;
       o.conn_pad4 = true; o.max_all = 2 * c->fvec.block;
       o.sort_local = dbg.tile_sort >= 0 ? dbg.tile_sort != 0 : true;
       c->fvec.ok = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
                                    nb_ptr.data(), nb.data(), 0, nodw, 48 * 1024, c->fvec.block, false, tsV, o);
       if (c->fvec.ok) {
-        c->fvec.ntile = tsV.ntile; c->fvec.lds = tsV.lds_bytes; c->fvec.redundancy = tsV.point_redundancy; c->fvec.lpe = maxval;
+        c->fvec.ntile = tsV.ntile; c->fvec.lds = tsV.lds_bytes; c->fvec.lds_alt = tsV.lds_bytes_alt; c->fvec.redundancy = tsV.point_redundancy; c->fvec.lpe = maxval;
         c->fvec.conn_stride = tsV.conn_stride;
         // persistent LDS-DMA form: PhaseFracture / MicroPhaseFracture / LinearElasticity, workgroups of 192 or 256
         const bool model_ok = p->model == FA_LINEAR_ELASTICITY || p->model == FA_PHASE_FRACTURE || p->model == FA_MICRO_PHASE_FRACTURE;
@@ -1151,6 +1153,11 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
     P.tpairs = emat->tpairs; P.tents = emat->tents; P.ntile3 = emat->ntile; P.tile_lds = emat->lds;
     P.tile_block = emat->block; P.emat_lpe = emat->lpe;
     P.conn_stride = emat->conn_stride; P.persistent = 0;
+    // force-vector kernel: FA_FVEC_ATOMIC=1 adds into one LDS row per node with atomics (a quarter of the buffer, one more
+    // workgroup per CU) instead of ordered per-element rows: measured 1.25 against 1.27 ms on cfg3, not worth giving up the
+    // repeatable sum, so it stays opt-in
+    P.fvec_atomic = (emat == &c->fvec && !(a->flags & FA_DETERMINISTIC) && (c->dbg.fvec_atomic > 0) && !emat->persistent) ? 1 : 0;
+    if (P.fvec_atomic) P.tile_lds = emat->lds_alt;
     if (emat->persistent) {
       P.persistent = 1; P.st_maxn = emat->maxn; P.st_maxe = emat->maxe; P.tile_lds = emat->plds;
     }

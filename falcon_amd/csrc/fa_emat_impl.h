@@ -520,7 +520,11 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
   const bool ext_state = PF && (SP::model(P) == 2 || SP::model(P) == 3 || SP::model(P) >= 5);
   // [n_own][V][NDOF], the rows of a node padded to an odd number of doubles: consecutive nodes then start on 16
   // different bank pairs (12 doubles per node = 4 starting banks = 4-way conflicts on every write of phase 1)
-  const int SB = (V * NDOF) | 1;
+  // P.fvec_atomic: one f row per owned node, added to with LDS atomics, instead of one row per (node, incident element)
+  // summed in order afterwards -- a quarter of the buffer, so twice the workgroups fit a CU; not bitwise repeatable
+  // (FA_DETERMINISTIC keeps the ordered form)
+  const bool atom = P.fvec_atomic != 0;
+  const int SB = atom ? NDOF : ((V * NDOF) | 1);
   double* sBuf = sExt + (ext_state ? 2 * n_all : 0);
   int* sNode = reinterpret_cast<int*>(sBuf + n_own * SB);
   uint16_t* sConn = reinterpret_cast<uint16_t*>(sNode + n_own);
@@ -544,6 +548,7 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
     }
   }
   for (int i = tid; i < n_el * CS; i += BLK) sConn[i] = P.tconn[(int64_t)elem_off * CS + i];
+  if (atom) for (int i = tid; i < n_own * NDOF; i += BLK) sBuf[i] = 0.0;
   const bool hist_model = PF && (SP::model(P) == 1 || SP::model(P) >= 4);
   double H0v[NIP];
 #pragma unroll
@@ -613,10 +618,17 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
 #pragma unroll
     for (int a = 0; a < NPE; a++) {
       if (li[a] < n_own) {
-        double* dst = sBuf + li[a] * SB + (int)((es >> (8 * a)) & 0xFFu) * NDOF;
+        if (atom) {
+          double* dst = sBuf + li[a] * NDOF;
 #pragma unroll
-        for (int i = 0; i < RANK; i++) dst[i] = A.fu[a][i];
-        if constexpr (PF) dst[RANK] = A.fp[a];
+          for (int i = 0; i < RANK; i++) atomicAdd(&dst[i], A.fu[a][i]);
+          if constexpr (PF) atomicAdd(&dst[RANK], A.fp[a]);
+        } else {
+          double* dst = sBuf + li[a] * SB + (int)((es >> (8 * a)) & 0xFFu) * NDOF;
+#pragma unroll
+          for (int i = 0; i < RANK; i++) dst[i] = A.fu[a][i];
+          if constexpr (PF) dst[RANK] = A.fp[a];
+        }
       }
     }
   }
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
   // ---- phase 2: f_int rows of the owned nodes (:748-749), summed in element order ----
   for (int i = tid; i < n_own * NDOF; i += BLK) {
     const int ia = i / NDOF, c = i - ia * NDOF;
-    const int val = (int)sVal[ia];
+    const int val = atom ? 1 : (int)sVal[ia];
     const double* src = sBuf + ia * SB + c;
     double s = 0.0;
     for (int k = 0; k < val; k++) s += src[k * NDOF];

@@ -9,6 +9,7 @@ namespace fa {
 struct TileSet {
   int ntile = 0;
   int lds_bytes = 0;                     // largest LDS footprint of a tile (dynamic shared memory of the launch)
+  int lds_bytes_alt = 0;                 // the same with TileOpts::own_doubles_alt doubles per owned node
   std::vector<int32_t> tinfo;            // kTileInfo words per tile
   std::vector<int32_t> tnodes;           // nodes of every tile, owned ones first
   std::vector<int32_t> telems;           // elements of every tile, ascending; bit 31 = tile stores the per-point outputs
@@ -35,6 +36,7 @@ struct TileOpts {
   bool no_tab = false;      // no shape tables in LDS
   bool no_f_image = false;  // no f image in LDS
   int own_doubles = 0;      // extra doubles of LDS per owned node
+  int own_doubles_alt = -1; // >= 0: a second, smaller per-node footprint the same tiles are also launched with (lds_bytes_alt)
   int max_all = 0;          // > 0: at most this many nodes (owned + halo) per tile
   bool conn_pad4 = false;   // tconn rows padded to 4 entries (8 bytes per element: the persistent kernels fetch them with
                             // two 4-byte LDS-DMA loads)

@@ -177,15 +177,17 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
 
   // ---- offsets ----
   std::vector<int64_t> o_node((size_t)ntile + 1, 0), o_el((size_t)ntile + 1, 0), o_pair((size_t)ntile + 1, 0), o_ent((size_t)ntile + 1, 0);
-  int64_t max_bytes = 0;
+  int64_t max_bytes = 0, max_bytes_alt = 0;
   for (int64_t t = 0; t < ntile; t++) {
     const int32_t* c = counts.data() + t * 5;
+    if (opts.own_doubles_alt >= 0)
+      max_bytes_alt = std::max(max_bytes_alt, C.bytes(c[2], c[1], c[0]) - 8 * (int64_t)c[0] * (opts.own_doubles - opts.own_doubles_alt));
     o_node[t + 1] = o_node[t] + c[1]; o_el[t + 1] = o_el[t] + c[2]; o_pair[t + 1] = o_pair[t] + c[3]; o_ent[t + 1] = o_ent[t] + c[4];
     max_bytes = std::max(max_bytes, C.bytes(c[2], c[1], c[0]));
   }
   const int64_t lim = 0x7FFFFFF0LL;
   if (o_node[ntile] > lim || o_el[ntile] * 4 > lim || o_pair[ntile] * 4 > lim || o_ent[ntile] > lim) return false;
-  T.ntile = (int)ntile; T.lds_bytes = (int)max_bytes;
+  T.ntile = (int)ntile; T.lds_bytes = (int)max_bytes; T.lds_bytes_alt = (int)max_bytes_alt;
   T.tinfo.assign((size_t)ntile * kTileInfo, 0);
   T.tnodes.assign((size_t)o_node[ntile], 0); T.telems.assign((size_t)o_el[ntile], 0);
   const int cs = opts.conn_pad4 ? 4 : npe;
