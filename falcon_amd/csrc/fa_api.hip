@@ -409,16 +409,26 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     return fail(FA_ERR_ARG, "unknown shape id %d", p->shape);
   c->launch = launcher_for(p->shape);
   c->rank = sh.rank; c->npe = sh.npe; c->nip = sh.nip; c->str = (sh.rank == 2) ? 4 : 6;
-  if (p->model < FA_LINEAR_ELASTICITY || p->model > FA_MICRO_PHASE_FRACTURE_EXTIT) return fail(FA_ERR_ARG, "invalid model %d", p->model);
+  if (p->model < FA_LINEAR_ELASTICITY || p->model > FA_GRADIENT_DAMAGE) return fail(FA_ERR_ARG, "invalid model %d", p->model);
+  const bool gd = p->model == FA_GRADIENT_DAMAGE;
   const bool pf = p->model != FA_LINEAR_ELASTICITY;
   c->ndofpn = pf ? sh.rank + 1 : sh.rank;
   c->srows = pf ? c->str + 1 : c->str;
   // material <-> model pairing (PhaseFractureModel.cpp:193-194 dynamicCast<PhaseFractureMaterial>)
   if (!pf && p->material != FA_HOOKE) return fail(FA_ERR_ARG, "LinearElasticity needs material Hooke");
-  if (pf && p->material == FA_HOOKE) return fail(FA_ERR_ARG, "phase-field models need a PhaseFractureMaterial");
-  if (p->material < FA_HOOKE || p->material > FA_MIEHE_PHASE) return fail(FA_ERR_ARG, "Invalid material: %d", p->material);
+  if (pf && !gd && p->material == FA_HOOKE) return fail(FA_ERR_ARG, "phase-field models need a PhaseFractureMaterial");
+  if (p->material < FA_HOOKE || p->material > FA_DAMAGE) return fail(FA_ERR_ARG, "Invalid material: %d", p->material);
+  // GradientDamageModel.cpp:205-206 dynamicCast<DamageMaterial>
+  if (gd != (p->material == FA_DAMAGE)) return fail(FA_ERR_ARG, "GradientDamage needs material Damage, and only GradientDamage takes it");
+  if (gd) {
+    if (p->softening < FA_SOFT_PERFECT || p->softening > FA_SOFT_EXPONENTIAL2)
+      return fail(FA_ERR_ARG, "unexpected definition of softening law!!! Supported here: perfect, linear1, linear2, exponential1, exponential2");
+    if (!(p->kappa_i > 0.0)) return fail(FA_ERR_ARG, "Damage: kappaI (or ft / young) must be positive");
+    if ((p->softening == FA_SOFT_LINEAR1 || p->softening == FA_SOFT_LINEAR2 || p->softening == FA_SOFT_EXPONENTIAL2) && !(p->kappa_c > p->kappa_i))
+      return fail(FA_ERR_ARG, "Damage: kappaC must exceed kappaI");
+  }
   c->fam = !pf ? fa::FAM_LE : (p->material == FA_MIEHE_PHASE ? fa::FAM_PF_MIEHE : fa::FAM_PF_ISO);
-  if (p->model >= FA_MICRO_PHASE_FRACTURE) {
+  if (p->model >= FA_MICRO_PHASE_FRACTURE && p->model <= FA_MICRO_PHASE_FRACTURE_EXTIT) {
     // AmorPhase's split update leaves stiffN untouched in tension (AmorPhaseMaterial.cpp:239-268), so the reference's
     // result depends on what an earlier Gauss point of its serial loop left there: not reproducible in parallel
     if (p->material == FA_AMOR_PHASE) return fail(FA_ERR_UNSUPPORTED, "MicroPhaseFracture* with AmorPhase depends on the serial Gauss-point order of the reference (stale stiffN); not available on the device");
@@ -439,7 +449,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   {
     const double E = p->young, gc = p->gc, l0 = p->l0, sT = p->sigma_t;
     double cw = 2, eta = 0, pe = 2, a1 = 2, a2 = -0.5, a3 = 0, psi0 = 0;
-    if (pf) {
+    if (pf && !gd) {
       switch (p->frac_type) {
         case FA_AT1: cw = 8.0 / 3.0; eta = 1.0; psi0 = (3. * gc) / (16. * l0); break;
         case FA_AT2: break;
@@ -474,6 +484,10 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   const bool plain = p->model == FA_PHASE_FRACTURE || p->model == FA_MICRO_PHASE_FRACTURE;
   P.keep2 = plain && p->keep_off_diags;
   P.keep3 = plain ? (p->keep_off_diags != 0) : (pf ? 1 : 0);
+  if (gd) {                                            // all four blocks (GradientDamageModel.cpp:577-583); c2 = c (:438, :563)
+    P.keep2 = 1; P.keep3 = 1; P.c2 = p->length_scale; P.psi0 = 0.0; P.gcl = 0.0;
+    P.soft = p->softening; P.kI = p->kappa_i; P.kC = p->kappa_c; P.sA = p->soft_alpha; P.sB = p->soft_beta;
+  }
 
   // ---- inverse connectivity, element-ascending per node ----
   std::vector<int32_t> n2e_ptr(nnode + 1, 0), n2e_ent((size_t)nel * npe);
@@ -818,7 +832,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
 
     if (P.canon && wanted && nel > 0) {
       const bool keepK = P.keep2 || P.keep3;
-      const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE;
+      const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE && p->model != FA_GRADIENT_DAMAGE;
       // lane order of the pair phase: sorted by element count with (a,b)/(b,a) sharing a lane, except on triangle
       // meshes, where (node, neighbour) order with the staged row write-out measured faster (Triangle6: 1.9 / 2.45 ms)
       const bool tri = p->shape == FA_TRI3_G1 || p->shape == FA_TRI3_G3 || p->shape == FA_TRI6_G3;
@@ -873,7 +887,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     const bool wanted = dbg.emat >= 0 ? dbg.emat != 0 : false;
     if (shape_ok && wanted && P.canon && nel > 0) {
       const bool keepK = P.keep2 || P.keep3;
-      const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE;
+      const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE && p->model != FA_GRADIENT_DAMAGE;
       const int nodw = fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0);
       const int budget = dbg.emat_lds > 0 ? dbg.emat_lds : 80 * 1024;
       auto lpe_of = [&](int want) { return (want == 2 && sh.nip % 2 == 0) ? 2 : 1; };
@@ -902,7 +916,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     const bool shape_ok = p->shape == FA_QUAD4_G2 || p->shape == FA_TRI3_G1;
     const bool wanted = dbg.fvec >= 0 ? dbg.fvec != 0 : true;
     if (shape_ok && wanted && canonical_dofs && c->ndof == nnode * nd && nel > 0 && maxval <= 8) {
-      const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE;
+      const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE && p->model != FA_GRADIENT_DAMAGE;
       const int nodw = fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0);
       c->fvec.block = (dbg.fvec_blk == 128 || dbg.fvec_blk == 192 || dbg.fvec_blk == 256 || dbg.fvec_blk == 320) ? dbg.fvec_blk : 192;
       fa::TileOpts o;
@@ -1322,6 +1336,7 @@ extern "C" fa_status fa_strain_table(fa_ctx* c, double* table, double* weights, 
 
 extern "C" fa_status fa_stress_table(fa_ctx* c, double* table, double* weights, void* stream) {
   if (!c || !table || !weights) return fail(FA_ERR_ARG, "null argument");
+  if (c->prob.model == FA_GRADIENT_DAMAGE) return fail(FA_ERR_UNSUPPORTED, "fa_stress_table: not provided for GradientDamage (its strain cache holds the nonlocal equivalent strain, not a degradation)");
   if (!c->d_strain) return fail(FA_ERR_ARG, "no strain cache: assemble with FA_STORE_STRAIN first");
   FA_ON_DEVICE(c->prob.device);
   if (c->nnode == 0) return FA_OK;

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
       const int64_t dp = dof(n, RANK);
       L.phi[a] = P.state[dp];
       if (P.model == 2 || P.model == 3) { L.phi0[a] = P.state0[dp]; L.phiX[a] = P.stateX[dp]; }
-      else if (P.model >= 5) L.phiX[a] = P.stateX[dp];
+      else if ((P.model == 5 || P.model == 6)) L.phiX[a] = P.stateX[dp];
     }
   }
   __syncthreads();
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
 #pragma unroll
         for (int i = 0; i < RANK; i++) gphi[i] += ga[i] * ph;
         if (P.model == 2 || P.model == 3) { pf0 += Na * L.phi0[a]; pfX += Na * L.phiX[a]; }
-        else if (P.model >= 5) pfX += Na * L.phiX[a];
+        else if ((P.model == 5 || P.model == 6)) pfX += Na * L.phiX[a];
       }
     }
     const int64_t ipoint = e * NIP + ip;               // initializeIPMPMap_, PhaseFractureModel.cpp:1070-1093

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(BLK) FA_EMAT_ATTR void assemble_emat(const Params P
   double* sSlot = smem;
   double* sNod = sSlot + n_el * SLOTW;
   double* sExt = sNod + n_all * NODW;                 // phi of state0 / state00 (stateExt_), Ext variants only
-  const bool ext_state = PF && (SP::model(P) == 2 || SP::model(P) == 3 || SP::model(P) >= 5);
+  const bool ext_state = PF && (SP::model(P) == 2 || SP::model(P) == 3 || (SP::model(P) == 5 || SP::model(P) == 6));
   long long* sRow = reinterpret_cast<long long*>(sExt + (ext_state ? 2 * n_all : 0));   // first CSR entry of every owned node
   int* sDeg = reinterpret_cast<int*>(sRow + n_own);                                     // neighbours of every owned node
   uint16_t* sConn = reinterpret_cast<uint16_t*>(sDeg + ((n_own + 1) & ~1));
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(BLK) FA_EMAT_ATTR void assemble_emat(const Params P
       const int64_t dp = n * NDOF + RANK;
       nd[2 * RANK] = P.state[dp];
       if (SP::model(P) == 2 || SP::model(P) == 3) { sExt[2 * i] = P.state0[dp]; sExt[2 * i + 1] = P.stateX[dp]; }
-      else if (SP::model(P) >= 5) { sExt[2 * i] = 0.0; sExt[2 * i + 1] = P.stateX[dp]; }
+      else if ((SP::model(P) == 5 || SP::model(P) == 6)) { sExt[2 * i] = 0.0; sExt[2 * i + 1] = P.stateX[dp]; }
     }
   }
   if constexpr (WANT_K) {
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
 
   double* sNod = smem;
   double* sExt = sNod + n_all * NODW;
-  const bool ext_state = PF && (SP::model(P) == 2 || SP::model(P) == 3 || SP::model(P) >= 5);
+  const bool ext_state = PF && (SP::model(P) == 2 || SP::model(P) == 3 || (SP::model(P) == 5 || SP::model(P) == 6));
   // [n_own][V][NDOF], the rows of a node padded to an odd number of doubles: consecutive nodes then start on 16
   // different bank pairs (12 doubles per node = 4 starting banks = 4-way conflicts on every write of phase 1)
   // P.fvec_atomic: one f row per owned node, added to with LDS atomics, instead of one row per (node, incident element)
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
       const int64_t dp = n * NDOF + RANK;
       nd[2 * RANK] = P.state[dp];
       if (SP::model(P) == 2 || SP::model(P) == 3) { sExt[2 * i] = P.state0[dp]; sExt[2 * i + 1] = P.stateX[dp]; }
-      else if (SP::model(P) >= 5) { sExt[2 * i] = 0.0; sExt[2 * i + 1] = P.stateX[dp]; }
+      else if ((SP::model(P) == 5 || SP::model(P) == 6)) { sExt[2 * i] = 0.0; sExt[2 * i + 1] = P.stateX[dp]; }
     }
   }
   for (int i = tid; i < n_el * CS; i += BLK) sConn[i] = P.tconn[(int64_t)elem_off * CS + i];

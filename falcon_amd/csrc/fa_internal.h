@@ -170,6 +170,9 @@ struct Params {
   double gcl, c2;            // gc/(cw*l0), 2*gc*l0/cw
   double eta, a1, a2, a3, psi0, beta, dt, dt0;
   double alpha;              // micromorphic penalty beta * gc / l0 (MicroPhaseFractureModel.cpp:579)
+  // gradient damage (model 7): softening law and its parameters (DamageMaterial.cpp:157-268); c2 holds the length scale c
+  int32_t soft, soft_pad;
+  double kI, kC, sA, sB;
 };
 
 // launchers, one translation unit per shape (fa_kernels_<shape>.hip)

@@ -145,7 +145,7 @@ __device__ __forceinline__ void gather_elem(const Params& P, const int32_t (&cn)
     if constexpr (PF) {
       E.phi[a] = P.state[dofs[RANK]];
       if (SP::model(P) == 2 || SP::model(P) == 3) { E.phi0[a] = P.state0[dofs[RANK]]; E.phiX[a] = P.stateX[dofs[RANK]]; }
-      else if (SP::model(P) >= 5) { E.phi0[a] = 0.0; E.phiX[a] = P.stateX[dofs[RANK]]; }   // stateExt_ only
+      else if ((SP::model(P) == 5 || SP::model(P) == 6)) { E.phi0[a] = 0.0; E.phiX[a] = P.stateX[dofs[RANK]]; }   // stateExt_ only
       else { E.phi0[a] = 0.0; E.phiX[a] = 0.0; }
     }
   }
@@ -454,7 +454,7 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
     iso_update<RANK, S, SP>(P, eps, 1.0, r.d0, r.d1, r.d3, r.sig, sp, Psi);
   } else {
     if constexpr (FAM == FAM_PF_MIEHE) {
-      if (SP::model(P) >= 4) {                          // MicroPhaseFractureModel.cpp:656-830 (general-tangent family only)
+      if (SP::model(P) >= 4 && SP::model(P) <= 6) {     // MicroPhaseFractureModel.cpp:656-830 (general-tangent family only)
         MicroOut mo;
         double gphi = 1.0, dhist = 0.0;
         const bool ext = SP::model(P) != 4;               // MicroPhaseFractureExtModel.cpp:656-940, ...ExtItModel.cpp:712
@@ -515,6 +515,72 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
         if constexpr (KEEP) {
 #pragma unroll
           for (int c = 0; c < S; c++) r.sp[c] = sp[c];
+        }
+        return;
+      }
+    }
+    if constexpr (FAM == FAM_PF_ISO) {
+      if (SP::model(P) == 7) {
+        // GradientDamageModel.cpp:500-560 with DamageMaterial::update (DamageMaterial.cpp:356-440), eqvStrain = Energy:
+        // pf is the nonlocal equivalent strain at the point (strain_(strCount, ipoint), :524), H0 the committed kappa
+        // with the loading flag in its sign bit.
+        double e0v[S];
+        double psi2 = 0.0;                                // eps^t D0 eps; D0 eps = dEpsBardEps (:700-705) = stiff0 eps (:547)
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+          double acc = 0.0;
+#pragma unroll
+          for (int j = 0; j < S; j++) {
+            const double dij = (i < RANK && j < RANK) ? ((i == j) ? P.hd0 : P.hd1) : ((i == j) ? P.hd3 : 0.0);
+            acc += dij * eps[j];
+          }
+          e0v[i] = acc; psi2 += acc * eps[i];
+        }
+        const double eq = 0.5 * psi2;                     // getEquiStrain, StrainEnergy (:645-650)
+        const double kappa0 = fabs(H0);
+        const int load0 = (H0 < 0.0) ? 1 : 0;
+        const double fl = pf - kappa0;                    // loading function (:383)
+        double kappa; int load;
+        if (fl == 0.0)     { kappa = kappa0; load = load0; }
+        else if (fl > 0.0) { kappa = pf; load = (kappa < P.kI) ? 0 : 1; }
+        else               { kappa = kappa0; load = 0; }
+        double omega = 0.0, domega = 0.0;                 // damageEvolution_ / getdOmegadKappa (:712-855, :1044-1260)
+        {
+          const double Ki = P.kI, Kc = P.kC, K = kappa;
+          if (P.soft == 0) {
+            if (K >= Ki) omega = 1.0 - Ki / K;
+            domega = (K < Ki) ? 0.0 : Ki / (K * K);
+          } else if (P.soft == 1) {
+            if (K >= Ki) { omega = K > Kc ? 1.0 : Kc * (K - Ki) / (K * (Kc - Ki)); if (omega == 1.0) omega = 0.999; }
+            domega = (K < Kc) ? (Ki * Kc) / ((Kc - Ki) * K * K) : 0.0;
+          } else if (P.soft == 2) {
+            if (K >= Ki) omega = K > Kc ? 0.999 : (K - Ki) / (Kc - Ki);
+            domega = (K < Kc) ? 1.0 / (Kc - Ki) : 0.0;
+          } else if (P.soft == 3) {
+            const double ex = exp(-P.sB * (K - Ki));
+            if (K >= Ki) omega = 1.0 - (Ki / K) * (1.0 - P.sA + P.sA * ex);
+            const double a = Ki / (K * K), b = a * K, c = P.sA * ex;
+            domega = a * (1.0 - P.sA + c) + P.sB * b * c;
+          } else {
+            const double ex = exp((Ki - K) / (Kc - Ki));
+            if (K >= Ki) omega = 1.0 - (Ki / K) * ex;
+            const double d = Ki / (K * K);
+            domega = d * ex + d * K * ex / (Kc - Ki);
+          }
+        }
+        const double s1 = 1.0 - omega;
+        r.d0 = s1 * P.hd0; r.d1 = s1 * P.hd1; r.d3 = s1 * P.hd3;      // stiff = (1 - omega) elasticMod_ (:421)
+#pragma unroll
+        for (int i = 0; i < S; i++) r.sig[i] = s1 * e0v[i];
+        if (P.strain != nullptr && write) P.strain[ipoint * srows + STR] = pf;
+        if (write) P.hist_new[ipoint] = load ? -kappa : kappa;
+        r.c1 = 1.0;                                       // K4 = w (N N^t + c Be^t Be) (:563)
+        r.cf = pf - eq;                                   // f2 = -w eq N + K4 eqv (:570-575)
+        r.dg = load ? -domega : 0.0;                      // K2 = -w dOmega Bd^t stiff0 eps N^t when loading (:551-558)
+        r.dgl = -1.0;                                     // K3 = -w N dEpsBardEps^t Bd (:545-547)
+        if constexpr (KEEP) {
+#pragma unroll
+          for (int c = 0; c < S; c++) r.sp[c] = e0v[c];
         }
         return;
       }
@@ -664,7 +730,7 @@ __device__ __forceinline__ void ip_point_core(const Params& P, int64_t e, int ip
 #pragma unroll
       for (int a = 0; a < NPE; a++) { pf0 += Nv[a] * E.phi0[a]; pfX += Nv[a] * E.phiX[a]; }
     }
-    if (SP::model(P) >= 5) {
+    if ((SP::model(P) == 5 || SP::model(P) == 6)) {
 #pragma unroll
       for (int a = 0; a < NPE; a++) pfX += Nv[a] * E.phiX[a];
     }

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   double* sRec = smem;
   double* sNod = sRec + (WANT_K ? n_el * SLOTW : 0);   // GET_INT_VECTOR passes keep no records
   double* sExt = sNod + n_all * NODW;                 // phi of state0 / state00 (stateExt_), Ext variants only
-  const bool ext_state = PF && (SP::model(P) == 2 || SP::model(P) == 3 || SP::model(P) >= 5);
+  const bool ext_state = PF && (SP::model(P) == 2 || SP::model(P) == 3 || (SP::model(P) == 5 || SP::model(P) == 6));
   double* sF   = sExt + (ext_state ? 2 * n_all : 0);
   const int n_rows = P.tile_sym ? n_all : n_own;      // cross-tile mirror lanes also write rows of halo nodes
   // grouped pair lanes (3-D elastic kernels): f image for every tile node -- the pair lanes add K_ba u_a for halo nodes b too
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
       const int64_t dp = n * NDOF + RANK;
       nd[2 * RANK] = P.state[dp];
       if (SP::model(P) == 2 || SP::model(P) == 3) { sExt[2 * i] = P.state0[dp]; sExt[2 * i + 1] = P.stateX[dp]; }
-      else if (SP::model(P) >= 5) { sExt[2 * i] = 0.0; sExt[2 * i + 1] = P.stateX[dp]; }
+      else if ((SP::model(P) == 5 || SP::model(P) == 6)) { sExt[2 * i] = 0.0; sExt[2 * i + 1] = P.stateX[dp]; }
     }
   }
   for (int i = tid; i < n_f * NDOF; i += BLK) sF[i] = 0.0;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
         const double Na = tabN[ip * NPE + a];
         pf += Na * nd[2 * RANK];
         if (SP::model(P) == 2 || SP::model(P) == 3) { pf0 += Na * sExt[2 * (int)lc[a]]; pfX += Na * sExt[2 * (int)lc[a] + 1]; }
-        else if (SP::model(P) >= 5) pfX += Na * sExt[2 * (int)lc[a] + 1];
+        else if ((SP::model(P) == 5 || SP::model(P) == 6)) pfX += Na * sExt[2 * (int)lc[a] + 1];
       }
     }
     double inv[RANK][RANK], det;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
 #pragma unroll
         for (int i = 0; i < RANK; i++) gphi[i] += ga[i] * ph;
         if (SP::model(P) == 2 || SP::model(P) == 3) { pf0 += Na * sExt[2 * (int)lc[a]]; pfX += Na * sExt[2 * (int)lc[a] + 1]; }
-        else if (SP::model(P) >= 5) pfX += Na * sExt[2 * (int)lc[a] + 1];
+        else if ((SP::model(P) == 5 || SP::model(P) == 6)) pfX += Na * sExt[2 * (int)lc[a] + 1];
       }
     }
     const int64_t ipoint = e * NIP + ip;               // initializeIPMPMap_, PhaseFractureModel.cpp:1070-1093

@@ -37,11 +37,23 @@ enum { FA_LINEAR_ELASTICITY = 0, FA_PHASE_FRACTURE = 1, FA_PHASE_FRACTURE_EXT = 
        FA_MICRO_PHASE_FRACTURE_EXT = 5,   /* "MicroPhaseFractureExt", MicroPhaseFractureExtModel.cpp:523-952: g from
                                       the damage solved for the extrapolated micromorphic variable; the caller passes
                                       stateExt_ (:553-566) as state00; state0 / dt / dt0 are not read; penalty 6500 */
-       FA_MICRO_PHASE_FRACTURE_EXTIT = 6  /* "MicroPhaseFractureExtIt", MicroPhaseFractureExtItModel.cpp: the same plus
-                                      errExt_ = sum (pf - pfEx)^2 (:712) returned through err_ext */ };
+       FA_MICRO_PHASE_FRACTURE_EXTIT = 6, /* "MicroPhaseFractureExtIt", MicroPhaseFractureExtItModel.cpp: the same plus
+                                      errExt_ = sum (pf - pfEx)^2 (:712) returned through err_ext */
+       FA_GRADIENT_DAMAGE = 7             /* "GradientDamage", GradientDamageModel.cpp:368-588: implicit
+                                      gradient-enhanced damage, dofs = displacements + the nonlocal equivalent strain
+                                      (where the phase-field models have phi); material FA_DAMAGE; history = kappa with
+                                      the loading flag (DamageMaterial.cpp:356-440) in its sign bit; all four blocks
+                                      K1..K4 are written (pattern as with keepOffDiags) */ };
 
 /* material.type, newMaterial, src/materials/Material.cpp:233-244 */
-enum { FA_HOOKE = 0, FA_AMOR_PHASE = 1, FA_BOURDIN_PHASE = 2, FA_MIEHE_PHASE = 3 };
+enum { FA_HOOKE = 0, FA_AMOR_PHASE = 1, FA_BOURDIN_PHASE = 2, FA_MIEHE_PHASE = 3,
+       FA_DAMAGE = 4 /* "Damage", src/materials/DamageMaterial.cpp, with eqvStrain = "Energy" (:645-650, :700-705): the
+                        only equivalent-strain definition whose derivative is the undamaged stress D0 eps, i.e. the one
+                        Voigt vector the Gauss-point records carry; Mazars / vonMises need a second one and are refused */ };
+
+/* softening (DamageMaterial.cpp:182-268; the laws are the free functions of :1044-1260) */
+enum { FA_SOFT_PERFECT = 0, FA_SOFT_LINEAR1 = 1, FA_SOFT_LINEAR2 = 2, FA_SOFT_EXPONENTIAL1 = 3 /* alpha, beta */,
+       FA_SOFT_EXPONENTIAL2 = 4 /* kappaC */ };
 
 /* material.state, src/materials/HookeMaterial.cpp:92-103 */
 enum { FA_PLANE_STRAIN = 0, FA_PLANE_STRESS = 1 };
@@ -91,6 +103,10 @@ typedef struct {
   int64_t ndof;                                /* total dofs of the matrix (0 => nnode*ndofpn)          */
   int32_t pattern_kind;
   int32_t device;                              /* HIP device ordinal                                    */
+  /* FA_GRADIENT_DAMAGE / FA_DAMAGE only (DamageMaterial.cpp:157-268): softening law and its parameters, kappaI (or
+   * ft / young), kappaC, alpha, beta, and the gradient parameter c = lengthScale (GradientDamageModel.cpp:438) */
+  int32_t softening;
+  double  kappa_i, kappa_c, soft_alpha, soft_beta, length_scale;
 } fa_problem;
 
 typedef struct {

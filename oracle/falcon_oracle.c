@@ -830,6 +830,154 @@ static int add_block(const int64_t* row_ptr, const int32_t* col_idx, double* val
 /* ------------------------------------------------------------------------- */
 /* The hot loop                                                              */
 /* ------------------------------------------------------------------------- */
+/* ---- DamageMaterial, restated for eqvStrain = Energy (DamageMaterial.cpp:645-650, :700-705) ---- */
+static double damage_evolution(const fo_config* c, double K) {          /* damageEvolution_, :802-855, laws :1044-1290 */
+  const double Ki = c->kappa_i, Kc = c->kappa_c;
+  if (K < Ki) return 0.0;
+  switch (c->softening) {
+    case FO_SOFT_PERFECT: return 1.0 - Ki / K;
+    case FO_SOFT_LINEAR1: { double omega = K > Kc ? 1.0 : Kc * (K - Ki) / (K * (Kc - Ki)); if (omega == 1.0) omega = 0.999; return omega; }
+    case FO_SOFT_LINEAR2: return K > Kc ? 0.999 : (K - Ki) / (Kc - Ki);
+    case FO_SOFT_EXPONENTIAL1: return 1.0 - (Ki / K) * (1.0 - c->soft_alpha + c->soft_alpha * exp(-c->soft_beta * (K - Ki)));
+    default: return 1.0 - (Ki / K) * exp((Ki - K) / (Kc - Ki));
+  }
+}
+static double damage_derivative(const fo_config* c, double K) {         /* getdOmegadKappa, :712-765 */
+  const double Ki = c->kappa_i, Kc = c->kappa_c;
+  switch (c->softening) {
+    case FO_SOFT_PERFECT: return (K < Ki) ? 0.0 : Ki / (K * K);
+    case FO_SOFT_LINEAR1: return (K < Kc) ? (Ki * Kc) / ((Kc - Ki) * K * K) : 0.0;
+    case FO_SOFT_LINEAR2: return (K < Kc) ? 1.0 / (Kc - Ki) : 0.0;
+    case FO_SOFT_EXPONENTIAL1: {
+      const double h = K - Ki, a = Ki / (K * K), b = a * K, cc = c->soft_alpha * exp(-c->soft_beta * h);
+      return a * (1.0 - c->soft_alpha + cc) + c->soft_beta * b * cc;
+    }
+    default: { const double a = Ki - K, b = Kc - Ki, cc = exp(a / b), d = Ki / (K * K); return d * cc + d * K * cc / b; }
+  }
+}
+
+/* GradientDamageModel::getMatrix_ (GradientDamageModel.cpp:368-588) with DamageMaterial::update (:356-440).
+ * hist_pre / hist_new: kappa, negative when the loading flag is set (preHist_.eqveps / preHist_.loading). */
+static int assemble_gd(const fo_config* cfg, const double* coords, const int32_t* conn, int64_t el_begin, int64_t el_end,
+                       const int64_t* row_ptr, const int32_t* col_idx, const double* state,
+                       const double* hist_pre, double* hist_new, double* strain_cache, double* Kval, double* force) {
+  shape_t sh;
+  if (shape_init(&sh, cfg->shape)) return -1;
+  if (cfg->material != FO_DAMAGE) FAIL("GradientDamage needs the Damage material");
+  const int rank = sh.rank, nodeCount = sh.npe, ipCount = sh.nip;
+  const int strCount = STRAIN_COUNTS[rank];
+  const int dispCount = nodeCount * rank, eqvCount = nodeCount, ndofpn = rank + 1, srows = strCount + 1;
+  const int mbuilder = (Kval != NULL);
+  const double c = cfg->length_scale;
+  double stiff0[MAXSTR * MAXSTR];
+  if (hooke_stiff(rank, cfg->state, cfg->young, cfg->poisson, stiff0)) return -1;   /* giveElasticMatrix, :445 */
+
+  static __thread double grads[MAXNIP][MAXNPE][3];
+  static __thread double bd[MAXSTR * MAXND], DB[MAXSTR * MAXND];
+  static __thread double elemMat1[MAXND * MAXND], elemMat2[MAXND * MAXNPE], elemMat3[MAXNPE * MAXND], elemMat4[MAXNPE * MAXNPE];
+  double xc[MAXNPE][3], ipWeights[MAXNIP], disp[MAXND], eqv[MAXNPE];
+  double stiff[MAXSTR * MAXSTR], stress[MAXSTR], strain[MAXSTR], d0e[MAXSTR];
+  double elemForce1[MAXND], elemForce2[MAXNPE];
+  int64_t dispDofs[MAXND], eqvDofs[MAXNPE];
+
+  for (int64_t ie = el_begin; ie < el_end; ie++) {
+    const int32_t* inodes = conn + ie * nodeCount;
+    for (int a = 0; a < nodeCount; a++) {
+      for (int i = 0; i < 3; i++) xc[a][i] = (i < rank) ? coords[(int64_t)inodes[a] * rank + i] : 0.0;
+      for (int i = 0; i < rank; i++) dispDofs[a * rank + i] = (int64_t)inodes[a] * ndofpn + i;
+      eqvDofs[a] = (int64_t)inodes[a] * ndofpn + rank;
+    }
+    if (shape_gradients(&sh, (const double (*)[3])xc, grads, ipWeights)) return -1;
+    for (int i = 0; i < dispCount; i++) disp[i] = state[dispDofs[i]];
+    for (int a = 0; a < eqvCount; a++) eqv[a] = state[eqvDofs[a]];
+    memset(elemForce1, 0, sizeof elemForce1); memset(elemForce2, 0, sizeof elemForce2);
+    memset(elemMat1, 0, sizeof(double) * dispCount * dispCount); memset(elemMat2, 0, sizeof(double) * dispCount * eqvCount);
+    memset(elemMat3, 0, sizeof(double) * eqvCount * dispCount); memset(elemMat4, 0, sizeof(double) * eqvCount * eqvCount);
+
+    for (int ip = 0; ip < ipCount; ip++) {
+      const int64_t ipoint = ie * ipCount + ip;
+      fill_B(rank, nodeCount, (const double (*)[3])grads[ip], bd);
+      for (int cc = 0; cc < strCount; cc++) {
+        double s = 0.0;
+        for (int j = 0; j < dispCount; j++) s += bd[cc * dispCount + j] * disp[j];
+        strain[cc] = s;
+      }
+      const double* Nip = sh.N[ip];
+      const double eqvIp = dotn(eqvCount, Nip, eqv);                     /* strain_(strCount, ipoint), :524 */
+      if (strain_cache) {
+        for (int cc = 0; cc < strCount; cc++) strain_cache[ipoint * srows + cc] = strain[cc];
+        strain_cache[ipoint * srows + strCount] = eqvIp;
+      }
+      /* material_->update (DamageMaterial.cpp:356-440), nonlocal branch: equiStrain = strain[n] */
+      const double kappa0 = fabs(hist_pre[ipoint]);
+      const int load0 = hist_pre[ipoint] < 0.0;
+      const double f = eqvIp - kappa0;
+      double kappa; int load;
+      if (f == 0.0) { kappa = kappa0; load = load0; }
+      else if (f > 0.0) { kappa = eqvIp; load = (kappa < cfg->kappa_i) ? 0 : 1; }
+      else { kappa = kappa0; load = 0; }
+      const double omega = damage_evolution(cfg, kappa);
+      for (int i = 0; i < strCount * strCount; i++) stiff[i] = (1.0 - omega) * stiff0[i];
+      matvec(strCount, stiff, strain, stress);
+      hist_new[ipoint] = load ? -kappa : kappa;
+
+      const double wip = ipWeights[ip];
+      matvec(strCount, stiff0, strain, d0e);                              /* stiff0 eps = dEpsBardEps (Energy), :700-705 */
+      if (mbuilder) {
+        for (int cc = 0; cc < strCount; cc++) for (int j = 0; j < dispCount; j++) {      /* elemMat1 += wip bdt stiff bd */
+          double s = 0.0;
+          for (int k = 0; k < strCount; k++) s += stiff[cc * strCount + k] * bd[k * dispCount + j];
+          DB[cc * dispCount + j] = s;
+        }
+        for (int i = 0; i < dispCount; i++) for (int j = 0; j < dispCount; j++) {
+          double s = 0.0;
+          for (int cc = 0; cc < strCount; cc++) s += bd[cc * dispCount + i] * DB[cc * dispCount + j];
+          elemMat1[i * dispCount + j] += wip * s;
+        }
+        for (int a = 0; a < eqvCount; a++) for (int j = 0; j < dispCount; j++) {         /* elemMat3 -= wip (N (x) dEpsBardEps) bd */
+          double s = 0.0;
+          for (int cc = 0; cc < strCount; cc++) s += d0e[cc] * bd[cc * dispCount + j];
+          elemMat3[a * dispCount + j] -= wip * (Nip[a] * s);
+        }
+        if (load) {                                                        /* isLoading(ipoint): newHist_.loading, :549 */
+          const double dOmega = damage_derivative(cfg, kappa);
+          for (int i = 0; i < dispCount; i++) {
+            double s = 0.0;
+            for (int cc = 0; cc < strCount; cc++) s += bd[cc * dispCount + i] * d0e[cc];
+            for (int b = 0; b < eqvCount; b++) elemMat2[i * eqvCount + b] -= wip * dOmega * (s * Nip[b]);
+          }
+        }
+      }
+      for (int a = 0; a < eqvCount; a++) for (int b = 0; b < eqvCount; b++) {            /* elemMat4, always (:563) */
+        double s = 0.0;
+        for (int i = 0; i < rank; i++) s += grads[ip][a][i] * grads[ip][b][i];
+        elemMat4[a * eqvCount + b] += wip * (Nip[a] * Nip[b] + c * s);
+      }
+      const double equiStrain = 0.5 * dotn(strCount, strain, d0e);         /* getEquiStrain, StrainEnergy */
+      for (int i = 0; i < dispCount; i++) {
+        double s = 0.0;
+        for (int cc = 0; cc < strCount; cc++) s += bd[cc * dispCount + i] * stress[cc];
+        elemForce1[i] += wip * s;
+      }
+      for (int a = 0; a < eqvCount; a++) elemForce2[a] -= wip * equiStrain * Nip[a];
+    }
+    for (int a = 0; a < eqvCount; a++) {                                   /* elemForce2 += elemMat4 eqv (:577) */
+      double s = 0.0;
+      for (int b = 0; b < eqvCount; b++) s += elemMat4[a * eqvCount + b] * eqv[b];
+      elemForce2[a] += s;
+    }
+    if (mbuilder) {
+      if (add_block(row_ptr, col_idx, Kval, dispCount, dispDofs, dispCount, dispDofs, elemMat1)) return -1;
+      if (add_block(row_ptr, col_idx, Kval, dispCount, dispDofs, eqvCount, eqvDofs, elemMat2)) return -1;
+      if (add_block(row_ptr, col_idx, Kval, eqvCount, eqvDofs, dispCount, dispDofs, elemMat3)) return -1;
+      if (add_block(row_ptr, col_idx, Kval, eqvCount, eqvDofs, eqvCount, eqvDofs, elemMat4)) return -1;
+    }
+    for (int i = 0; i < dispCount; i++) force[dispDofs[i]] += elemForce1[i];
+    for (int a = 0; a < eqvCount; a++) force[eqvDofs[a]] += elemForce2[a];
+  }
+  return 0;
+}
+
 int fo_assemble(const fo_config* cfg,
                 int nnode, const double* coords,
                 int64_t nel, const int32_t* conn,
@@ -841,6 +989,9 @@ int fo_assemble(const fo_config* cfg,
                 double* strain_cache,
                 double* Kval, double* force, double* err_ext) {
   (void)nnode; (void)nel;
+  if (cfg->model == FO_GRADIENT_DAMAGE)
+    return assemble_gd(cfg, coords, conn, el_begin, el_end, row_ptr, col_idx, state, hist_pre, hist_new, strain_cache,
+                       Kval, force);
   shape_t sh;
   if (shape_init(&sh, cfg->shape)) return -1;
   const int rank = sh.rank, nodeCount = sh.npe, ipCount = sh.nip;

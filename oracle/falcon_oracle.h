@@ -45,11 +45,16 @@ enum {
   FO_PHASE_FRACTURE_EXTIT= 3,
   FO_MICRO_PHASE_FRACTURE= 4,  /* MicroPhaseFractureModel.cpp:502-851 (micromorphic: local damage d by Newton) */
   FO_MICRO_EXT           = 5,  /* MicroPhaseFractureExtModel.cpp:523-952: g from the extrapolated micromorphic variable */
-  FO_MICRO_EXTIT         = 6   /* MicroPhaseFractureExtItModel.cpp: the same + errExt_ (pass stateExt_ as state00 for both) */
+  FO_MICRO_EXTIT         = 6,  /* MicroPhaseFractureExtItModel.cpp: the same + errExt_ (pass stateExt_ as state00 for both) */
+  FO_GRADIENT_DAMAGE     = 7   /* GradientDamageModel.cpp:368-588 with DamageMaterial (eqvStrain = Energy); the history
+                                  arrays carry kappa with the loading flag of DamageMaterial.cpp:356-440 in the sign bit */
 };
 
 /* material ids: newMaterial, src/materials/Material.cpp:233-244 */
-enum { FO_HOOKE = 0, FO_AMOR = 1, FO_BOURDIN = 2, FO_MIEHE = 3 };
+enum { FO_HOOKE = 0, FO_AMOR = 1, FO_BOURDIN = 2, FO_MIEHE = 3, FO_DAMAGE = 4 };
+
+/* DamageMaterial softening laws restated (DamageMaterial.cpp:1044-1290) */
+enum { FO_SOFT_PERFECT = 0, FO_SOFT_LINEAR1 = 1, FO_SOFT_LINEAR2 = 2, FO_SOFT_EXPONENTIAL1 = 3, FO_SOFT_EXPONENTIAL2 = 4 };
 
 /* 2D problem state (HookeMaterial.cpp:92-103) */
 enum { FO_PLANE_STRAIN = 0, FO_PLANE_STRESS = 1 };
@@ -71,6 +76,9 @@ typedef struct {
   int    frac_type;      /* FO_AT1...                */
   double gc, l0, sigma_t, beta;
   int    keep_off_diags; /* PhaseFracture only       */
+  /* GradientDamage / Damage (DamageMaterial.cpp:157-268) */
+  int    softening;
+  double kappa_i, kappa_c, soft_alpha, soft_beta, length_scale;
 } fo_config;
 
 typedef struct {

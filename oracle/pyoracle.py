@@ -17,10 +17,11 @@ _LIB = os.path.join(_HERE, "libfalcon_oracle.so")
 TRI3_G1, TRI3_G3, QUAD4_G2, QUAD8_G3, QUAD8_G2, TRI6_G3, HEX8_G2, HEX20_G3, HEX20_G2 = range(9)
 # models
 (LINEAR_ELASTICITY, PHASE_FRACTURE, PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT, MICRO_PHASE_FRACTURE, MICRO_EXT,
- MICRO_EXTIT) = range(7)
-HISTORY_MODELS = (PHASE_FRACTURE, MICRO_PHASE_FRACTURE, MICRO_EXT, MICRO_EXTIT)
+ MICRO_EXTIT, GRADIENT_DAMAGE) = range(8)
+HISTORY_MODELS = (PHASE_FRACTURE, MICRO_PHASE_FRACTURE, MICRO_EXT, MICRO_EXTIT, GRADIENT_DAMAGE)
 # materials
-HOOKE, AMOR, BOURDIN, MIEHE = range(4)
+HOOKE, AMOR, BOURDIN, MIEHE, DAMAGE = range(5)
+SOFT_PERFECT, SOFT_LINEAR1, SOFT_LINEAR2, SOFT_EXPONENTIAL1, SOFT_EXPONENTIAL2 = range(5)
 PLANE_STRAIN, PLANE_STRESS = 0, 1
 AT1, AT2, CZM_LINEAR, CZM_EXPONENTIAL, CZM_CORNELISSEN, CZM_HYPERBOLIC = range(6)
 PATTERN_FULL, PATTERN_WRITTEN = 0, 1
@@ -31,7 +32,9 @@ class Config(C.Structure):
                 ("young", C.c_double), ("poisson", C.c_double),
                 ("frac_type", C.c_int),
                 ("gc", C.c_double), ("l0", C.c_double), ("sigma_t", C.c_double), ("beta", C.c_double),
-                ("keep_off_diags", C.c_int)]
+                ("keep_off_diags", C.c_int),
+                ("softening", C.c_int), ("kappa_i", C.c_double), ("kappa_c", C.c_double), ("soft_alpha", C.c_double),
+                ("soft_beta", C.c_double), ("length_scale", C.c_double)]
 
 
 class ShapeInfo(C.Structure):
@@ -131,9 +134,10 @@ def ndof_per_node(model, rank):
 
 
 def make_config(shape, model, material, state=PLANE_STRAIN, young=210e3, poisson=0.3, frac_type=AT2,
-                gc=2.7, l0=0.015, sigma_t=0.0, beta=6500.0, keep_off_diags=0):
+                gc=2.7, l0=0.015, sigma_t=0.0, beta=6500.0, keep_off_diags=0, softening=0, kappa_i=0.0, kappa_c=0.0,
+                soft_alpha=0.0, soft_beta=0.0, length_scale=0.0):
     return Config(shape, model, material, state, young, poisson, frac_type, gc, l0, sigma_t, beta,
-                  int(keep_off_diags))
+                  int(keep_off_diags), softening, kappa_i, kappa_c, soft_alpha, soft_beta, length_scale)
 
 
 def psi0(cfg):
@@ -162,6 +166,8 @@ def keep_code(cfg):
         return 1 if cfg.keep_off_diags else 0
     if cfg.model in (PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT, MICRO_EXT, MICRO_EXTIT):
         return 2
+    if cfg.model == GRADIENT_DAMAGE:
+        return 1
     return 0
 
 

@@ -229,3 +229,54 @@ def micro_newton(psi, target, d, frac, alpha):
         if abs(res) <= 1e-4 or it == 100:
             return d, dg, ddg
         d -= res / jac
+
+
+# ---- GradientDamageModel::getMatrix_ (GradientDamageModel.cpp:368-588) with DamageMaterial (eqvStrain = Energy) ----
+def damage_law(soft, Ki, Kc, al, be, K):
+    """(omega, dOmega/dKappa): DamageMaterial.cpp:1044-1289, laws Perfect, Linear1, Linear2, Exponential1, Exponential2."""
+    if soft == 0:
+        return (0.0 if K < Ki else 1 - Ki / K), (0.0 if K < Ki else Ki / K ** 2)
+    if soft == 1:
+        om = 0.0 if K < Ki else (1.0 if K > Kc else Kc * (K - Ki) / (K * (Kc - Ki)))
+        return (0.999 if om == 1.0 else om), (Ki * Kc / ((Kc - Ki) * K ** 2) if K < Kc else 0.0)
+    if soft == 2:
+        return (0.0 if K < Ki else (0.999 if K > Kc else (K - Ki) / (Kc - Ki))), (1 / (Kc - Ki) if K < Kc else 0.0)
+    if soft == 3:
+        ex = np.exp(-be * (K - Ki))
+        return (0.0 if K < Ki else 1 - Ki / K * (1 - al + al * ex)), Ki / K ** 2 * (1 - al + al * ex) + be * Ki / K * al * ex
+    ex = np.exp((Ki - K) / (Kc - Ki))
+    return (0.0 if K < Ki else 1 - Ki / K * ex), Ki / K ** 2 * ex + Ki / K * ex / (Kc - Ki)
+
+
+def element_gd(x, N, dN, w, u, eqv, kap0, load0, D0, law, c, want_K=True):
+    """returns K1, K2, K3, K4, f1, f2, kappa, loading.  law = (soft, Ki, Kc, alpha, beta)."""
+    npe, rank = x.shape
+    nd = rank * npe
+    K1 = np.zeros((nd, nd)); K2 = np.zeros((nd, npe)); K3 = np.zeros((npe, nd)); K4 = np.zeros((npe, npe))
+    f1 = np.zeros(nd); f2 = np.zeros(npe); kap = np.zeros(len(w)); ld = np.zeros(len(w), dtype=int)
+    for ip in range(len(w)):
+        J = x.T @ dN[ip]
+        g = dN[ip] @ np.linalg.inv(J)
+        wip = w[ip] * np.linalg.det(J)
+        B = B_matrix(g)
+        eps = B @ u
+        Nip = N[ip]
+        e_nl = Nip @ eqv
+        f = e_nl - kap0[ip]
+        if f == 0.0:
+            kap[ip], ld[ip] = kap0[ip], load0[ip]
+        elif f > 0.0:
+            kap[ip], ld[ip] = e_nl, int(e_nl >= law[1])
+        else:
+            kap[ip], ld[ip] = kap0[ip], 0
+        om, dom = damage_law(*law, kap[ip])
+        D = (1 - om) * D0
+        K1 += wip * B.T @ D @ B
+        K3 -= wip * np.outer(Nip, (D0 @ eps) @ B)
+        if ld[ip]:
+            K2 -= wip * dom * B.T @ D0 @ np.outer(eps, Nip)
+        K4 += wip * (np.outer(Nip, Nip) + c * g @ g.T)
+        f1 += wip * B.T @ (D @ eps)
+        f2 -= wip * 0.5 * eps @ D0 @ eps * Nip
+    f2 += K4 @ eqv
+    return K1, K2, K3, K4, f1, f2, kap, ld

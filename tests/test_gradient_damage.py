@@ -1,0 +1,257 @@
+"""GradientDamageModel::getMatrix_ (GradientDamageModel.cpp:368-588) with DamageMaterial (eqvStrain = Energy):
+the oracle against closed forms, against an independent numpy restatement and against finite differences of its own
+f_int; the HIP path against the oracle.  Parity unpinned against the reference itself (no numeric fixtures exist for
+this model): the closed forms and the numpy restatement are the independent evidence.
+
+History convention of both implementations: kappa, negated when the loading flag of DamageMaterial.cpp:356-440 is set."""
+import numpy as np
+import pytest
+
+from falcon_amd import meshgen
+from oracle import pyoracle as po
+from tests import np_ref
+from tests.test_oracle_kat import GRID, csr_dense
+
+E, NU = 210.0, 0.3
+LAWS = {po.SOFT_PERFECT: dict(kappa_i=1.0e-3),
+        po.SOFT_LINEAR1: dict(kappa_i=1.0e-3, kappa_c=4.0e-3),
+        po.SOFT_LINEAR2: dict(kappa_i=1.0e-3, kappa_c=4.0e-3),
+        po.SOFT_EXPONENTIAL1: dict(kappa_i=1.0e-3, soft_alpha=0.95, soft_beta=300.0),
+        po.SOFT_EXPONENTIAL2: dict(kappa_i=1.0e-3, kappa_c=6.0e-3)}
+
+
+def gd_config(shape, soft, state2d=po.PLANE_STRAIN, c=0.02):
+    return po.make_config(shape, po.GRADIENT_DAMAGE, po.DAMAGE, state=state2d, young=E, poisson=NU, softening=soft,
+                          length_scale=c, **LAWS[soft])
+
+
+def gd_state(coords, rank, seed=3):
+    """displacements ~5e-3, nonlocal equivalent strain in [0, 6e-3] (kappaI = 1e-3: both sides of the threshold)."""
+    nn = coords.shape[0]
+    st = meshgen.smooth_state(coords, rank + 1, seed=seed, amp=5e-3, noise=1e-4, l0=0.3).reshape(nn, rank + 1)
+    rng = np.random.default_rng(seed)
+    st[:, rank] = 3e-3 + 2.5e-3 * np.sin(3.0 * coords[:, 0] + 1.0) * np.cos(2.0 * coords[:, 1]) + rng.uniform(-4e-4, 4e-4, nn)
+    return st.ravel()
+
+
+def gd_history(n, seed=11):
+    rng = np.random.default_rng(seed)
+    kap = rng.uniform(0.0, 5e-3, n)
+    load = (rng.uniform(size=n) < 0.5) & (kap >= 1e-3)
+    return np.where(load, -kap, kap)
+
+
+def test_softening_laws_closed_form_and_derivative():
+    """omega(kappa) of a one-element uniform state, read back from K1 = (1 - omega) K_elastic; d omega / d kappa of the
+    numpy restatement is the derivative of its omega (central difference), away from the kinks."""
+    coords, conn = meshgen.grid_quad4(1, 1)
+    rp, ci = po.pattern(4, conn, 3, 2)
+    st = np.zeros(12)
+    for soft, kw in LAWS.items():
+        cfg = gd_config(po.QUAD4_G2, soft)
+        Ki, Kc = kw["kappa_i"], kw.get("kappa_c", 0.0)
+        al, be = kw.get("soft_alpha", 0.0), kw.get("soft_beta", 0.0)
+        for kap in (0.5e-3, 1.0e-3, 2.0e-3, 3.9e-3, 7.0e-3):
+            st[2::3] = kap                                            # uniform nonlocal strain above the old kappa = 0
+            out = po.assemble(cfg, coords, conn, rp, ci, st)
+            K = csr_dense(rp, ci, out["K"])
+            ud = np.array([0, 1, 3, 4, 6, 7, 9, 10])
+            st0 = st.copy(); st0[2::3] = 0.0
+            Kel = csr_dense(rp, ci, po.assemble(cfg, coords, conn, rp, ci, st0)["K"])[np.ix_(ud, ud)]
+            om = {po.SOFT_PERFECT: 1 - Ki / kap,
+                  po.SOFT_LINEAR1: 0.999 if kap > Kc else Kc * (kap - Ki) / (kap * (Kc - Ki)),
+                  po.SOFT_LINEAR2: 0.999 if kap > Kc else (kap - Ki) / (Kc - Ki),
+                  po.SOFT_EXPONENTIAL1: 1 - Ki / kap * (1 - al + al * np.exp(-be * (kap - Ki))),
+                  po.SOFT_EXPONENTIAL2: 1 - Ki / kap * np.exp((Ki - kap) / (Kc - Ki) if Kc else 0.0)}[soft]
+            if kap < Ki:
+                om = 0.0
+            assert np.allclose(K[np.ix_(ud, ud)], (1 - om) * Kel, rtol=1e-13, atol=1e-13 * np.abs(Kel).max()), (soft, kap)
+            assert np.allclose(out["hist_new"], kap if kap < Ki else -kap)        # loading flag once kappa >= kappaI
+            if abs(kap - Ki) > 1e-6 and (not Kc or abs(kap - Kc) > 2e-4):
+                h = 1e-8
+                fd = (np_ref.damage_law(soft, Ki, Kc, al, be, kap + h)[0] - np_ref.damage_law(soft, Ki, Kc, al, be, kap - h)[0]) / (2 * h)
+                an = np_ref.damage_law(soft, Ki, Kc, al, be, kap)[1]
+                if kap > Ki and not (Kc and kap > Kc):
+                    assert abs(fd - an) < 1e-5 * max(1.0, abs(an)), (soft, kap, fd, an)
+
+
+def test_uniaxial_element_closed_form():
+    """Unit square, plane strain, u_x = e x, uniform nonlocal strain k > kappa0: every block in closed form."""
+    coords, conn = meshgen.grid_quad4(1, 1)
+    rp, ci = po.pattern(4, conn, 3, 2)
+    e, k, c = 2e-3, 2.5e-3, 0.03
+    cfg = gd_config(po.QUAD4_G2, po.SOFT_EXPONENTIAL2, c=c)
+    Ki, Kc = 1e-3, 6e-3
+    st = np.zeros(12); st[0::3] = e * coords[:, 0]; st[2::3] = k
+    out = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=np.full(4, 1.5e-3))
+    a = E / ((1 + NU) * (1 - 2 * NU)); D00 = a * (1 - NU); D01 = a * NU
+    om = 1 - Ki / k * np.exp((Ki - k) / (Kc - Ki))
+    dom = Ki / k ** 2 * np.exp((Ki - k) / (Kc - Ki)) * (1 + k / (Kc - Ki))
+    f = out["f"].reshape(4, 3)
+    sx = (1 - om) * D00 * e
+    assert np.allclose(f[:, 0], sx * 0.5 * np.sign(coords[:, 0] - 0.5), rtol=1e-13)           # int B^t sigma over the unit square
+    sy = (1 - om) * D01 * e
+    assert np.allclose(f[:, 1], sy * 0.5 * np.sign(coords[:, 1] - 0.5), rtol=1e-13)
+    eq = 0.5 * D00 * e * e
+    assert np.allclose(f[:, 2], 0.25 * (k - eq), rtol=1e-13)                                  # int N (k - eq); grad k = 0
+    K = csr_dense(rp, ci, out["K"])
+    pd = np.array([2, 5, 8, 11]); ux = pd - 2; uy = pd - 1
+    assert np.allclose(K[np.ix_(pd, pd)].sum(axis=1), 0.25, rtol=1e-13)                       # rows of int N N^t sum to int N
+    x = np.array([1.0, -1.0, 1.0, -1.0]) if False else (coords[:, 0] - 0.5) * 2                # gradient part: c int grad N . grad N
+    assert abs(x @ K[np.ix_(pd, pd)] @ x - (4 * c + 1.0 / 3.0)) < 1e-13 * 4                   # int (2x-1)^2 = 1/3, |grad (2x-1)|^2 = 4
+    # K2 = -dOmega int B^t D0 eps N^t (loading), K3 = -int N (D0 eps)^t B
+    assert np.allclose(K[np.ix_(ux, pd)].sum(axis=1), -dom * D00 * e * 0.5 * np.sign(coords[:, 0] - 0.5), rtol=1e-12)
+    assert np.allclose(K[np.ix_(uy, pd)].sum(axis=1), -dom * D01 * e * 0.5 * np.sign(coords[:, 1] - 0.5), rtol=1e-12)
+    assert np.allclose(K[np.ix_(pd, ux)].sum(axis=0), -D00 * e * 0.5 * np.sign(coords[:, 0] - 0.5), rtol=1e-12)
+    assert np.allclose(out["hist_new"], -k)
+    # unloading: same state, older kappa above k -> secant with the old kappa, no K2, flag cleared
+    out2 = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=np.full(4, -3e-3))
+    K2 = csr_dense(rp, ci, out2["K"])
+    assert np.all(K2[np.ix_(ux, pd)] == 0.0) and np.allclose(out2["hist_new"], 3e-3)
+    om3 = 1 - Ki / 3e-3 * np.exp((Ki - 3e-3) / (Kc - Ki))
+    assert np.allclose(out2["f"].reshape(4, 3)[:, 0], (1 - om3) * D00 * e * 0.5 * np.sign(coords[:, 0] - 0.5), rtol=1e-13)
+    # f == 0 exactly: kappa and the flag of the old history are kept (DamageMaterial.cpp:393-397)
+    # (the interpolated N . eqv is k only to rounding, so the old history is taken from a first pass of the same state)
+    h1 = out["hist_new"]
+    for hist in (h1, np.abs(h1)):
+        out3 = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=hist)
+        assert np.array_equal(out3["hist_new"], hist)
+        assert (np.abs(csr_dense(rp, ci, out3["K"])[np.ix_(ux, pd)]).max() > 0) == (hist[0] < 0)
+
+
+@pytest.mark.parametrize("shape,soft", [(po.QUAD4_G2, po.SOFT_EXPONENTIAL2), (po.QUAD4_G2, po.SOFT_LINEAR1),
+                                        (po.TRI3_G1, po.SOFT_PERFECT), (po.HEX8_G2, po.SOFT_EXPONENTIAL1),
+                                        (po.QUAD8_G3, po.SOFT_LINEAR2), (po.TRI6_G3, po.SOFT_EXPONENTIAL2)])
+def test_oracle_vs_numpy_restatement(shape, soft):
+    rank, npe, nip, _ = po.shape_info(shape)
+    coords, conn = GRID[shape]()
+    coords = meshgen.distort(coords, conn, 0.12 if npe in (3, 4, 8) and shape != po.QUAD8_G3 else 0.05)
+    nn = coords.shape[0]; nd = rank + 1
+    cfg = gd_config(shape, soft)
+    rp, ci = po.pattern(nn, conn, nd, rank)
+    st = gd_state(coords, rank)
+    H0 = gd_history(conn.shape[0] * nip)
+    out = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=H0, want_strain=True)
+    N, dN, w = po.shape_tables(shape)
+    D0 = np_ref.hooke(rank, 0, E, NU)
+    kw = LAWS[soft]
+    law = (soft, kw["kappa_i"], kw.get("kappa_c", 0.0), kw.get("soft_alpha", 0.0), kw.get("soft_beta", 0.0))
+    ndof = nn * nd
+    K = np.zeros((ndof, ndof)); f = np.zeros(ndof); Hn = np.zeros_like(H0)
+    S = st.reshape(nn, nd)
+    for e, c in enumerate(conn):
+        ud = np.array([[n * nd + i for i in range(rank)] for n in c]).ravel(); pd = c * nd + rank
+        h = H0[e * nip:(e + 1) * nip]
+        K1, K2, K3, K4, f1, f2, kap, ld = np_ref.element_gd(coords[c], N, dN, w, S[c, :rank].ravel(), S[c, rank],
+                                                            np.abs(h), (h < 0).astype(int), D0, law, 0.02)
+        K[np.ix_(ud, ud)] += K1; K[np.ix_(pd, pd)] += K4
+        K[np.ix_(ud, pd)] += K2; K[np.ix_(pd, ud)] += K3
+        f[ud] += f1; f[pd] += f2; Hn[e * nip:(e + 1) * nip] = np.where(ld == 1, -kap, kap)
+    assert np.allclose(csr_dense(rp, ci, out["K"]), K, rtol=0, atol=1e-12 * np.abs(K).max())
+    assert np.allclose(out["f"], f, rtol=0, atol=1e-12 * np.abs(f).max())
+    assert np.allclose(out["hist_new"], Hn, rtol=1e-13)
+    assert (Hn < 0).any() and (Hn > 0).any()                            # both loading and unloading points present
+    # force-only pass: same f and history, K untouched
+    out_f = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=H0, want_K=False)
+    assert np.array_equal(out_f["f"], out["f"]) and np.array_equal(out_f["hist_new"], out["hist_new"])
+
+
+def test_tangent_is_the_derivative_of_f_int_when_loading():
+    """All points loading (nonlocal strain above the old kappa and above kappaI): K = d f_int / d state."""
+    shape = po.QUAD4_G2
+    coords, conn = meshgen.grid_quad4(2, 2)
+    coords = meshgen.distort(coords, conn, 0.1)
+    nn = coords.shape[0]
+    cfg = gd_config(shape, po.SOFT_EXPONENTIAL2)
+    rp, ci = po.pattern(nn, conn, 3, 2)
+    st = gd_state(coords, 2)
+    st[2::3] = np.abs(st[2::3]) + 2e-3
+    H0 = np.full(conn.shape[0] * 4, 1.2e-3)
+    K = csr_dense(rp, ci, po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=H0)["K"])
+    h = 1e-7
+    for j in range(nn * 3):
+        sp = st.copy(); sp[j] += h; sm = st.copy(); sm[j] -= h
+        fd = (po.assemble(cfg, coords, conn, rp, ci, sp, hist_pre=H0, want_K=False)["f"]
+              - po.assemble(cfg, coords, conn, rp, ci, sm, hist_pre=H0, want_K=False)["f"]) / (2 * h)
+        assert np.allclose(fd, K[:, j], rtol=1e-5, atol=1e-6 * np.abs(K[:, j]).max() + 1e-9), j
+
+
+def test_refusals():
+    coords, conn = meshgen.grid_quad4(1, 1)
+    rp, ci = po.pattern(4, conn, 3, 2)
+    cfg = po.make_config(po.QUAD4_G2, po.GRADIENT_DAMAGE, po.AMOR, young=E, poisson=NU)
+    with pytest.raises(ValueError):
+        po.assemble(cfg, coords, conn, rp, ci, np.zeros(12))
+
+
+# ---------------------------------------------------------------- GPU parity ----------------------------------------------------------------
+GPU_MESH = {po.TRI3_G1: lambda: meshgen.grid_tri3(9, 7), po.QUAD4_G2: lambda: meshgen.grid_quad4(11, 9),
+            po.HEX8_G2: lambda: meshgen.grid_hex8(5, 4, 3), po.TRI6_G3: lambda: meshgen.grid_tri6(6, 5),
+            po.QUAD8_G3: lambda: meshgen.grid_quad8(7, 5), po.HEX20_G2: lambda: meshgen.grid_hex20(3, 3, 3)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,soft,state2d", [
+    (po.QUAD4_G2, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN), (po.QUAD4_G2, po.SOFT_LINEAR1, po.PLANE_STRESS),
+    (po.QUAD4_G2, po.SOFT_PERFECT, po.PLANE_STRAIN), (po.TRI3_G1, po.SOFT_LINEAR2, po.PLANE_STRAIN),
+    (po.TRI3_G1, po.SOFT_EXPONENTIAL1, po.PLANE_STRESS), (po.HEX8_G2, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN),
+    (po.HEX8_G2, po.SOFT_EXPONENTIAL1, po.PLANE_STRAIN), (po.TRI6_G3, po.SOFT_LINEAR1, po.PLANE_STRAIN),
+    (po.QUAD8_G3, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN), (po.HEX20_G2, po.SOFT_LINEAR2, po.PLANE_STRAIN)])
+def test_gpu_gradient_damage_parity(shape, soft, state2d):
+    """K + f pass, commit, K + f pass on the unchanged state (the f == 0 branch), then a force-only pass, each against
+    the oracle carrying its own history the same way."""
+    import torch
+    from falcon_amd import capi
+    from tests.conftest import rel_rowmax_err
+    TOL = 1e-12
+    rank, npe, nip, _ = po.shape_info(shape)
+    coords, conn = GPU_MESH[shape]()
+    coords = meshgen.distort(coords, conn, 0.15 if shape in (po.TRI3_G1, po.QUAD4_G2, po.HEX8_G2) else 0.06, 1)
+    cfg = gd_config(shape, soft, state2d)
+    st = gd_state(coords, rank)
+    H0 = gd_history(conn.shape[0] * nip)
+    asm = capi.Assembler(shape, capi.GRADIENT_DAMAGE, capi.DAMAGE, coords, conn, state=state2d, young=E, poisson=NU,
+                         softening=soft, length_scale=0.02, **LAWS[soft])
+    rp, ci = asm.pattern()
+    rpo, cio = po.pattern(coords.shape[0], conn, rank + 1, rank, po.PATTERN_FULL, po.keep_code(cfg))
+    assert np.array_equal(rp, rpo) and np.array_equal(ci, cio)
+    dev = torch.device("cuda", 0)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    asm.set_history(0, H0)
+    hist = H0
+    dst = d(st)
+    for step, want_K in enumerate((True, True, False)):
+        K = torch.full((asm.nnz,), 7.0, dtype=torch.float64, device=dev) if want_K else None
+        f = torch.full((asm.ndof,), -3.0, dtype=torch.float64, device=dev)
+        asm.assemble(dst, K, f, flags=capi.OVERWRITE | capi.STORE_STRAIN)
+        torch.cuda.synchronize()
+        ref = po.assemble(cfg, coords, conn, rpo, cio, st, hist_pre=hist, want_K=want_K, want_strain=True)
+        if want_K:
+            assert rel_rowmax_err(rp, K.cpu().numpy(), ref["K"]) < TOL, step
+        ef = np.abs(f.cpu().numpy() - ref["f"]).max() / np.abs(ref["f"]).max()
+        assert ef < TOL, (step, ef)
+        got_h = asm.get_history(1)
+        assert np.array_equal(got_h < 0, ref["hist_new"] < 0), step          # loading flags
+        assert np.abs(got_h - ref["hist_new"]).max() < TOL * np.abs(ref["hist_new"]).max(), step
+        sc = asm.get_strain_cache()
+        assert np.abs(sc - ref["strain"]).max() < TOL * np.abs(ref["strain"]).max()
+        if step == 0:
+            assert (ref["hist_new"] < 0).any() and (ref["hist_new"] > 0).any()
+            asm.commit()
+            hist = ref["hist_new"]
+            # the device's own committed history drives its second pass (exact f == 0 where it was loading)
+            asm_h = asm.get_history(0)
+            assert np.array_equal(asm_h, got_h)
+
+
+@pytest.mark.gpu
+def test_gpu_gradient_damage_refusals():
+    from falcon_amd import capi
+    coords, conn = meshgen.grid_quad4(3, 3)
+    with pytest.raises(capi.FaError):
+        capi.Assembler(capi.QUAD4_G2, capi.GRADIENT_DAMAGE, capi.AMOR_PHASE, coords, conn, young=E, poisson=NU)
+    with pytest.raises(capi.FaError):
+        capi.Assembler(capi.QUAD4_G2, capi.PHASE_FRACTURE, capi.DAMAGE, coords, conn, young=E, poisson=NU)
+    with pytest.raises(capi.FaError):
+        capi.Assembler(capi.QUAD4_G2, capi.GRADIENT_DAMAGE, capi.DAMAGE, coords, conn, young=E, poisson=NU,
+                       softening=capi.SOFT_LINEAR1, kappa_i=2e-3, kappa_c=1e-3)
