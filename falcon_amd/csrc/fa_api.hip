@@ -424,6 +424,8 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     if (p->softening < FA_SOFT_PERFECT || p->softening > FA_SOFT_EXPONENTIAL2)
       return fail(FA_ERR_ARG, "unexpected definition of softening law!!! Supported here: perfect, linear1, linear2, exponential1, exponential2");
     if (!(p->kappa_i > 0.0)) return fail(FA_ERR_ARG, "Damage: kappaI (or ft / young) must be positive");
+    if (p->eqv_strain != FA_EQV_ENERGY && p->eqv_strain != FA_EQV_MAZARS)
+      return fail(FA_ERR_ARG, "unexpected definition of equivalent strain!!! Available here: Energy, Mazars");
     if ((p->softening == FA_SOFT_LINEAR1 || p->softening == FA_SOFT_LINEAR2 || p->softening == FA_SOFT_EXPONENTIAL2) && !(p->kappa_c > p->kappa_i))
       return fail(FA_ERR_ARG, "Damage: kappaC must exceed kappaI");
   }
@@ -487,6 +489,8 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   if (gd) {                                            // all four blocks (GradientDamageModel.cpp:577-583); c2 = c (:438, :563)
     P.keep2 = 1; P.keep3 = 1; P.c2 = p->length_scale; P.psi0 = 0.0; P.gcl = 0.0;
     P.soft = p->softening; P.kI = p->kappa_i; P.kC = p->kappa_c; P.sA = p->soft_alpha; P.sB = p->soft_beta;
+    P.eqv = p->eqv_strain; P.k2sig = (p->eqv_strain != FA_EQV_ENERGY) ? 1 : 0;
+    P.pstress = (sh.rank == 2 && p->state == FA_PLANE_STRESS) ? 1 : 0; P.poiD = p->poisson / (p->poisson - 1.0);
   }
 
   // ---- inverse connectivity, element-ascending per node ----
@@ -1149,14 +1153,15 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   const bool keep = want_K && (P.keep2 || P.keep3);
   // bitwise reproducibility exists on the ordered row kernel only: the tile / cooperative / generic kernels add f_int
   // (and, the last two, K) with atomics whose order varies from run to run
-  const TileDev* emat = (a->flags & FA_FORCE_GENERIC) ? nullptr : (a->K_values ? (c->ematK.ok ? &c->ematK : nullptr) : (c->fvec.ok ? &c->fvec : (c->ematF.ok ? &c->ematF : nullptr)));
+  const TileDev* emat = (a->flags & FA_FORCE_GENERIC) ? nullptr : (a->K_values ? ((c->ematK.ok && !c->P.k2sig) ? &c->ematK : nullptr) : (c->fvec.ok ? &c->fvec : (c->ematF.ok ? &c->ematF : nullptr)));
   if ((a->flags & FA_DETERMINISTIC) && !emat && (!c->rows_path || (a->flags & FA_FORCE_GENERIC)))
     return fail(FA_ERR_UNSUPPORTED, "FA_DETERMINISTIC needs the row kernel (Triangle3/Gauss1, Quad4, Hex8 on a canonical node-major "
                                     "pattern): this context runs an atomic-scatter kernel");
   int path = c->coop ? fa::PATH_COOP : fa::PATH_GENERIC;
   if (c->rows_path && !(a->flags & FA_FORCE_GENERIC))
     path = (a->flags & FA_DETERMINISTIC) ? fa::PATH_ROWS_ORDERED : (c->patch_path ? fa::PATH_PATCH : (c->pair_path ? fa::PATH_ROWS_PAIR : fa::PATH_ROWS));
-  if (c->tile_path && (want_K || c->tile_force_only) && !(a->flags & (FA_FORCE_GENERIC | FA_DETERMINISTIC))) path = fa::PATH_TILES;
+  // (the tile kernel's pair lanes read K2 and K3 from one recorded vector: not for GradientDamage with a Mazars strain)
+  if (c->tile_path && (want_K || c->tile_force_only) && !(want_K && P.k2sig) && !(a->flags & (FA_FORCE_GENERIC | FA_DETERMINISTIC))) path = fa::PATH_TILES;
   // 3-D elastic tiles: f_int from the pair lanes (atomic adds to f) when K is assembled and no strain cache is asked for
   P.tile_fu = (path == fa::PATH_TILES && c->P.tile_fu && want_K && !(a->flags & FA_STORE_STRAIN)) ? 1 : 0;
   if (P.tile_fu && P.overwrite && c->nel > 0) HIP_TRY(hipMemsetAsync(a->f_int, 0, sizeof(double) * c->ndof, st));

@@ -270,7 +270,12 @@ __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
 #pragma unroll
             for (int c = 0; c < S; c++) spv[c] = m.sp[c];
             if (P.keep2) {                                              // K2 (:720)
-              Bt_vec<RANK, S>(wga, spv, tt);
+              if (P.k2sig) {                                            // GradientDamage / Mazars: D0 eps travels as sig / (1 - omega)
+                double sv[S];
+#pragma unroll
+                for (int c = 0; c < S; c++) sv[c] = m.sig[c];
+                Bt_vec<RANK, S>(wga, sv, tt);
+              } else Bt_vec<RANK, S>(wga, spv, tt);
 #pragma unroll
               for (int i = 0; i < RANK; i++) Kup[i] += (m.dg * tt[i]) * Nb;
             }

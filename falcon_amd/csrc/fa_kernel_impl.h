@@ -438,6 +438,71 @@ __device__ __forceinline__ void Bt_vec(const double (&ga)[RANK], const double (&
   }
 }
 
+// Mazars equivalent strain and its derivative as DamageMaterial computes them (DamageMaterial.cpp:618-642, :886-1032):
+// principal strains from the trigonometric solution of the characteristic cubic (Invariants.cpp:209-224,
+// MathUtils.cpp:150-181) with the reference's PI = 3.14159265 (Constants.cpp:13).  eps: xx, yy, gamma_xy in 2-D (zz = 0).
+template <int RANK, int S>
+__device__ __forceinline__ void mazars_strain(const Params& P, const double (&eps)[S], double& eq, double (&deq)[S]) {
+  double v[6];
+  if constexpr (RANK == 2) { v[0] = eps[0]; v[1] = eps[1]; v[2] = 0.0; v[3] = 0.5 * eps[2]; v[4] = 0.0; v[5] = 0.0; }
+  else { v[0] = eps[0]; v[1] = eps[1]; v[2] = eps[2]; v[3] = 0.5 * eps[3]; v[4] = 0.5 * eps[4]; v[5] = 0.5 * eps[5]; }
+  const double I1 = v[0] + v[1] + v[2];
+  const double I2 = v[0] * v[1] + v[1] * v[2] + v[2] * v[0] - (v[3] * v[3] + v[4] * v[4] + v[5] * v[5]);
+  const double I3 = v[0] * v[1] * v[2] + 2.0 * v[3] * v[4] * v[5] - v[0] * v[4] * v[4] - v[1] * v[5] * v[5] - v[2] * v[3] * v[3];
+  double pr[3];
+  {
+    const double RAD_120 = 0.6666666666666667 * 3.14159265;
+    const double aa = -I1, bb = I2, cc = -I3, aa3 = aa / 3.0;
+    const double q = (aa * aa - 3.0 * bb) / 9.0;
+    const double rr = (2.0 * aa * aa * aa - 9.0 * aa * bb + 27.0 * cc) / 54.0;
+    double help = rr / sqrt(q * q * q);
+    if (fabs(help) > 1.0) help = (help < 0) ? -1.0 : 1.0;
+    const double phi = acos(help), p = sqrt(q);
+    pr[0] = -2.0 * p * cos(phi / 3.0) - aa3;
+    pr[1] = -2.0 * p * cos(phi / 3.0 + RAD_120) - aa3;
+    pr[2] = -2.0 * p * cos(phi / 3.0 - RAD_120) - aa3;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) if (pr[i] > 0) s += pr[i] * pr[i];
+  eq = sqrt(s);
+#pragma unroll
+  for (int i = 0; i < S; i++) deq[i] = 0.0;
+  if constexpr (RANK == 3) {
+    if (eq < 1.e-16) return;
+    const double dI2[6] = { v[1] + v[2], v[2] + v[0], v[0] + v[1], -2. * v[3], -2. * v[4], -2. * v[5] };
+    const double dI3[6] = { v[1] * v[2] - v[4] * v[4], v[2] * v[0] - v[5] * v[5], v[0] * v[1] - v[3] * v[3],
+                            2.0 * (v[4] * v[5] - v[2] * v[3]), 2.0 * (v[5] * v[3] - v[0] * v[4]), 2.0 * (v[3] * v[4] - v[1] * v[5]) };
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const double vi = pr[i];
+      if (vi > 0) {
+        const double temp = 1.0 / (3.0 * vi * vi - 2.0 * I1 * vi + I2);
+#pragma unroll
+        for (int k = 0; k < 6; k++) deq[k] += vi * (temp * (vi * vi * (k < 3 ? 1.0 : 0.0) - vi * dI2[k] + dI3[k]));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) deq[k] *= (1.0 / eq);
+  } else {
+    const double exx = eps[0], eyy = eps[1], exy = 0.5 * eps[2];
+    const double exxMeyy = exx - eyy, exxPeyy = exx + eyy;
+    double d = sqrt(exxMeyy * exxMeyy + 4.0 * exy * exy);
+    double p0 = 0.5 * (exxPeyy + d), p1 = exxPeyy - p0, p2 = P.pstress ? P.poiD * exxPeyy : 0.0;
+    p0 = p0 < 0. ? 0. : p0; p1 = p1 < 0. ? 0. : p1; p2 = p2 < 0. ? 0. : p2;
+    const double den = sqrt(p0 * p0 + p1 * p1 + p2 * p2);
+    if (den < 1e-08) return;
+    const double denInv = 1. / den;
+    const double dedprin0 = p0 * denInv, dedprin1 = p1 * denInv, dedprin2 = p2 * denInv;
+    if (d == 0.0) d = 1.0;
+    const double fac = 0.5 / d;
+    const double de1dexx = 0.5 + fac * exxMeyy, de1deyy = 1.0 - de1dexx, de1dexy = 2.0 * fac * exy;
+    deq[0] = dedprin0 * de1dexx + dedprin1 * de1deyy + dedprin2 * P.poiD;
+    deq[1] = dedprin0 * de1deyy + dedprin1 * de1dexx + dedprin2 * P.poiD;
+    deq[2] = dedprin0 * de1dexy + dedprin1 * (-de1dexy);
+  }
+}
+
 // Constitutive part of one Gauss point: degradation, material update, history, phase-field coefficients
 // (PhaseFractureModel.cpp:656-703,714,728; Ext variants PhaseFractureExtModel.cpp:656-758).
 // pf / pf0 / pfX: phase field, old phase field and state00 (Ext) or stateExt_ (ExtIt) interpolated to the point.
@@ -536,7 +601,11 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
           }
           e0v[i] = acc; psi2 += acc * eps[i];
         }
-        const double eq = 0.5 * psi2;                     // getEquiStrain, StrainEnergy (:645-650)
+        double eq = 0.5 * psi2;                           // getEquiStrain, StrainEnergy (:645-650)
+        double deq[S];                                    // getdEpsBardEps
+#pragma unroll
+        for (int i = 0; i < S; i++) deq[i] = e0v[i];
+        if (P.eqv == 1) mazars_strain<RANK, S>(P, eps, eq, deq);
         const double kappa0 = fabs(H0);
         const int load0 = (H0 < 0.0) ? 1 : 0;
         const double fl = pf - kappa0;                    // loading function (:383)
@@ -577,10 +646,12 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
         r.c1 = 1.0;                                       // K4 = w (N N^t + c Be^t Be) (:563)
         r.cf = pf - eq;                                   // f2 = -w eq N + K4 eqv (:570-575)
         r.dg = load ? -domega : 0.0;                      // K2 = -w dOmega Bd^t stiff0 eps N^t when loading (:551-558)
+        // Mazars: sp carries d eq / d eps for K3, so K2 takes stiff0 eps from the stress, sig = (1 - omega) stiff0 eps
+        if (P.k2sig) r.dg = (load && s1 != 0.0) ? -domega / s1 : 0.0;
         r.dgl = -1.0;                                     // K3 = -w N dEpsBardEps^t Bd (:545-547)
         if constexpr (KEEP) {
 #pragma unroll
-          for (int c = 0; c < S; c++) r.sp[c] = e0v[c];
+          for (int c = 0; c < S; c++) r.sp[c] = deq[c];
         }
         return;
       }
@@ -849,7 +920,8 @@ __device__ __forceinline__ void accum_rows(const Params& P, const IpRec<SH, FAM,
       if constexpr (KEEP) {
         if (P.keep2) {                                                // K2 += w g' B^T (sigma+ (x) N) (:720)
           double t[RANK];
-          Bt_vec<RANK, S>(wga, r.sp, t);
+          if (P.k2sig) Bt_vec<RANK, S>(wga, r.sig, t);                 // GradientDamage / Mazars: D0 eps travels as sig / (1 - omega)
+          else Bt_vec<RANK, S>(wga, r.sp, t);
 #pragma unroll
           for (int i = 0; i < RANK; i++)
 #pragma unroll

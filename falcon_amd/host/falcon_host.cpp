@@ -380,7 +380,8 @@ class SolidAssemblyModel : public Model {
     if (!globdat.find(dofs_, Globdat::DOFS)) { dofs_ = std::make_shared<XDofSpace>(); globdat.set(Globdat::DOFS, dofs_); }
     static const char* DISP[3] = { "dx", "dy", "dz" };
     for (int i = 0; i < rank_; i++) types_.push_back(dofs_->addType(DISP[i]));
-    if (kind_ != FA_LINEAR_ELASTICITY) types_.push_back(dofs_->addType("phi"));
+    // the last DOF type: the phase field, or the nonlocal equivalent strain (GradientDamageModel.cpp:156-158)
+    if (kind_ != FA_LINEAR_ELASTICITY) types_.push_back(dofs_->addType(kind_ == FA_GRADIENT_DAMAGE ? "eqv" : "phi"));
     std::set<int32_t> uniq;
     for (int32_t ie : ielems_) uniq.insert(mesh_->elems[ie].begin(), mesh_->elems[ie].end());
     nodes_.assign(uniq.begin(), uniq.end());
@@ -395,10 +396,13 @@ class SolidAssemblyModel : public Model {
     else if (mtype == "AmorPhase") material_ = FA_AMOR_PHASE;
     else if (mtype == "BourdinPhase") material_ = FA_BOURDIN_PHASE;
     else if (mtype == "MiehePhase") material_ = FA_MIEHE_PHASE;
+    else if (mtype == "Damage") material_ = FA_DAMAGE;
     else throw Error(matProps.context, "Invalid material: " + mtype);
     if (mrank < 1 || mrank > 3) throw Error(matProps.context, "invalid material rank");
-    if (kind_ != FA_LINEAR_ELASTICITY) {
-      if (material_ == FA_HOOKE) throw Error(context, "material is not a PhaseFractureMaterial");   // dynamicCast, :194
+    if (kind_ == FA_GRADIENT_DAMAGE) {
+      if (material_ != FA_DAMAGE) throw Error(context, "material type is not a damage material");   // GradientDamageModel.cpp:181-189
+    } else if (kind_ != FA_LINEAR_ELASTICITY) {
+      if (material_ == FA_HOOKE || material_ == FA_DAMAGE) throw Error(context, "material is not a PhaseFractureMaterial");   // dynamicCast, :194
       myProps.find(keepOffDiags_, "keepOffDiags"); myConf.set("keepOffDiags", keepOffDiags_);
       std::string ft; myProps.get(ft, "fractureType");
       static const char* FT[6] = { "at1", "at2", "czmLinear", "czmExponential", "czmCornelissen", "czmHyperbolic" };
@@ -437,9 +441,39 @@ class SolidAssemblyModel : public Model {
       else if (st == "PLANE_STRESS") state_ = FA_PLANE_STRESS;
       else state_ = -1;                                     // AXISYMMETRIC etc.: HookeMaterial.cpp:262-265 throws later
     }
+    if (material_ == FA_DAMAGE) configureDamage_(matProps);
     std::shared_ptr<MatrixBuilder> mb;
     globdat.find(mb, "matrix0");
     createContext_(mb.get());
+  }
+
+  // DamageMaterial::configure (src/materials/DamageMaterial.cpp:157-315): same property names, ranges and messages
+  void configureDamage_(const Properties& props) {
+    if (!props.find(kappaI_, "kappaI")) {
+      double ft = 0.0; props.get(ft, "ft");
+      kappaI_ = ft / young_;
+    }
+    if (kappaI_ < 0) throw Error(props.context, "property `kappaI' out of range");
+    props.find(lengthScale_, "lengthScale");
+    std::string soft; props.get(soft, "softening");
+    static const char* LAWS[11] = { "perfect", "linear1", "linear2", "exponential1", "exponential2", "exponential2Reg", "power",
+                                    "hyperbolic", "expoEnergy", "polynomial", "multilinear" };
+    int law = -1;
+    for (int k = 0; k < 11; k++) if (soft == LAWS[k]) law = k;
+    if (law < 0)
+      throw Error("DamageMaterial::configure", "unexpected definition of softening law!!!\nSupported softening laws include: \n"
+                  "perfect, linear1, linear2, exponential1, exponential2, power, hyperbolic, polynomial, multilinear");
+    if (law > 4) throw Error(props.context, "softening law `" + soft + "' is not available on the GPU assembly path (perfect, linear1, linear2, exponential1, exponential2 are)");
+    softening_ = law;
+    if (law == FA_SOFT_EXPONENTIAL1) { props.get(softAlpha_, "alpha"); props.get(softBeta_, "beta"); }
+    if (law == FA_SOFT_EXPONENTIAL2 || law == FA_SOFT_LINEAR1 || law == FA_SOFT_LINEAR2) props.get(kappaC_, "kappaC");
+    std::string eq; props.get(eq, "eqvStrain");
+    if (eq == "Mazars") eqvStrain_ = FA_EQV_MAZARS;
+    else if (eq == "Energy") eqvStrain_ = FA_EQV_ENERGY;
+    else if (eq == "vonMises")
+      throw Error(props.context, "eqvStrain = vonMises is not available on the GPU assembly path (its derivative is a 6-vector for "
+                                 "2-D strains in the reference, DamageMaterial.cpp:677-683)");
+    else throw Error("DamageMaterial::configure", "unexpected definition of equivalent strain!!!\nAvailable ones are: Mazars, vonMises, Energy");
   }
 
   void getConfig(Properties& conf, const Properties&) const override {
@@ -461,6 +495,10 @@ class SolidAssemblyModel : public Model {
       return true;
     }
     if (action == Actions::GET_MATRIX2) throw Error(myName_, "GET_MATRIX2 is not served by the GPU assembly path");
+    if (kind_ == FA_GRADIENT_DAMAGE && action == "INIT") {                 // GradientDamageModel.cpp:321-330, setConstraints_ :682-724
+      if (shape_ == FA_TRI3_G1 || shape_ == FA_TRI3_G3 || shape_ == FA_QUAD4_G2) return true;   // linear shapes: nothing to constrain
+      throw Error(myName_, "the mid-node constraints of the nonlocal strain on higher-order shapes (setConstraints_) are not mirrored");
+    }
     if (action == Actions::COMMIT) {
       if (kind_ == FA_PHASE_FRACTURE || kind_ >= FA_MICRO_PHASE_FRACTURE) check_(fa_commit(ctx_));   // newHist_.swap(preHist_)
       if (kind_ == FA_PHASE_FRACTURE_EXT) dt0_ = dt_;                    // PhaseFractureExtModel.cpp:450
@@ -478,7 +516,7 @@ class SolidAssemblyModel : public Model {
       if (kind_ == FA_PHASE_FRACTURE_EXTIT) dt0_ = dt0;                  // Ext ignores dt0 (PhaseFractureExtModel.cpp:1339)
       return false;                                                      // sic: both reference models fall through
     }
-    if (action == Actions::SET_STEP_SIZE && kind_ >= FA_MICRO_PHASE_FRACTURE_EXT) {   // MicroPhaseFractureExtModel.cpp:1560-1577
+    if (action == Actions::SET_STEP_SIZE && (kind_ == FA_MICRO_PHASE_FRACTURE_EXT || kind_ == FA_MICRO_PHASE_FRACTURE_EXTIT)) {   // MicroPhaseFractureExtModel.cpp:1560-1577
       params.get(dt_, ActionParams::STEP_SIZE); params.get(dt0_, ActionParams::STEP_SIZE_0);
       return false;
     }
@@ -511,6 +549,8 @@ class SolidAssemblyModel : public Model {
     p.shape = shape_; p.model = kind_; p.material = material_; p.state = state_;
     p.young = young_; p.poisson = poisson_; p.frac_type = fracType_ < 0 ? FA_AT2 : fracType_;
     p.gc = gc_; p.l0 = l0_; p.sigma_t = sigmaT_; p.beta = beta_; p.keep_off_diags = keepOffDiags_ ? 1 : 0;
+    p.softening = softening_; p.kappa_i = kappaI_; p.kappa_c = kappaC_; p.soft_alpha = softAlpha_; p.soft_beta = softBeta_;
+    p.length_scale = lengthScale_; p.eqv_strain = eqvStrain_;
     p.nnode = (int64_t)nodes_.size(); p.coords = xc.data();
     p.nel = (int64_t)ielems_.size(); p.conn = conn.data();
     p.ndof = dofs_->dofCount();
@@ -592,6 +632,8 @@ class SolidAssemblyModel : public Model {
   bool keepOffDiags_ = false;
   double gc_ = 2.7, l0_ = 0.015, sigmaT_ = 0.0, beta_ = 6500.0;   // PhaseFractureModel.cpp:253-263, Ext :247
   double dt_ = 0.0, dt0_ = 0.0, errExt_ = 0.0;
+  int softening_ = 0, eqvStrain_ = 0;                         // DamageMaterial (GradientDamage)
+  double kappaI_ = 0.0, kappaC_ = 0.0, softAlpha_ = 0.0, softBeta_ = 0.0, lengthScale_ = 0.0;
   bool extFail_ = false; int oIter_ = 0, oMaxIter_ = 5000; double oTol_ = 1.e-3;
   std::vector<double> stateExt_;
   fa_ctx* ctx_ = nullptr;
@@ -612,6 +654,7 @@ void declareFalconSolidMechModels() {
   ModelFactory::declare("MicroPhaseFracture", &newSolidModel<FA_MICRO_PHASE_FRACTURE>);   // micromorphic variants
   ModelFactory::declare("MicroPhaseFractureExt", &newSolidModel<FA_MICRO_PHASE_FRACTURE_EXT>);
   ModelFactory::declare("MicroPhaseFractureExtIt", &newSolidModel<FA_MICRO_PHASE_FRACTURE_EXTIT>);
+  ModelFactory::declare("GradientDamage", &newSolidModel<FA_GRADIENT_DAMAGE>);   // GradientDamageModel.cpp:1455-1459
 }
 
 }  // namespace falcon_host

@@ -47,9 +47,13 @@ enum { FA_LINEAR_ELASTICITY = 0, FA_PHASE_FRACTURE = 1, FA_PHASE_FRACTURE_EXT = 
 
 /* material.type, newMaterial, src/materials/Material.cpp:233-244 */
 enum { FA_HOOKE = 0, FA_AMOR_PHASE = 1, FA_BOURDIN_PHASE = 2, FA_MIEHE_PHASE = 3,
-       FA_DAMAGE = 4 /* "Damage", src/materials/DamageMaterial.cpp, with eqvStrain = "Energy" (:645-650, :700-705): the
-                        only equivalent-strain definition whose derivative is the undamaged stress D0 eps, i.e. the one
-                        Voigt vector the Gauss-point records carry; Mazars / vonMises need a second one and are refused */ };
+       FA_DAMAGE = 4 /* "Damage", src/materials/DamageMaterial.cpp, with eqvStrain = "Energy" (:644-649, :698-703) or
+                        "Mazars" (:618-642, :886-1032; principal strains from the reference's trigonometric cubic solve
+                        with its PI = 3.14159265).  "vonMises" is refused: its derivative is a 6-vector for 2-D strains
+                        (:677-683), used out of bounds at GradientDamageModel.cpp:548 */ };
+
+/* eqvStrain of the Damage material */
+enum { FA_EQV_ENERGY = 0, FA_EQV_MAZARS = 1 };
 
 /* softening (DamageMaterial.cpp:182-268; the laws are the free functions of :1044-1260) */
 enum { FA_SOFT_PERFECT = 0, FA_SOFT_LINEAR1 = 1, FA_SOFT_LINEAR2 = 2, FA_SOFT_EXPONENTIAL1 = 3 /* alpha, beta */,
@@ -107,6 +111,7 @@ typedef struct {
    * ft / young), kappaC, alpha, beta, and the gradient parameter c = lengthScale (GradientDamageModel.cpp:438) */
   int32_t softening;
   double  kappa_i, kappa_c, soft_alpha, soft_beta, length_scale;
+  int32_t eqv_strain;                          /* FA_EQV_ENERGY / FA_EQV_MAZARS (eqvStrain, DamageMaterial.cpp:275-308) */
 } fa_problem;
 
 typedef struct {

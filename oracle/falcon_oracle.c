@@ -856,6 +856,109 @@ static double damage_derivative(const fo_config* c, double K) {         /* getdO
   }
 }
 
+/* ---- Mazars equivalent strain (DamageMaterial.cpp:618-642, getdEquidEpsMazars_ :886-1032), with what it calls:
+ * Invariants (src/util/Invariants.cpp:35-224) and solveCubicEqn (src/util/MathUtils.cpp:112-182), constants of
+ * src/util/Constants.cpp:13-18 -- PI is the reference's truncated literal, EPS = 1e-16 ---- */
+static const double REF_PI = 3.14159265;
+static void strain_v6(int rank, const double* strain, double* v6) {      /* Invariants::Invariants, isStrain = true */
+  v6[0] = strain[0]; v6[1] = strain[1]; v6[2] = strain[2]; v6[3] = 0.5 * strain[3]; v6[4] = 0.0; v6[5] = 0.0;
+  if (rank == 3) { v6[4] = 0.5 * strain[4]; v6[5] = 0.5 * strain[5]; }
+}
+static double inv_I1(const double* v) { return v[0] + v[1] + v[2]; }
+static double inv_I2(const double* v) { return v[0] * v[1] + v[1] * v[2] + v[2] * v[0] - (v[3] * v[3] + v[4] * v[4] + v[5] * v[5]); }
+static double inv_I3(const double* v) {
+  return v[0] * v[1] * v[2] + 2.0 * v[3] * v[4] * v[5] - v[0] * v[4] * v[4] - v[1] * v[5] * v[5] - v[2] * v[3] * v[3];
+}
+static int solve_cubic(double* ans, double a, double b, double c, double d) {   /* MathUtils.cpp:112-182 */
+  const double EPS = 1.e-16, RAD_120 = 0.6666666666666667 * REF_PI;
+  ans[0] = ans[1] = ans[2] = NAN;
+  if (fabs(a) < EPS) {
+    if (fabs(b) < EPS) { ans[0] = -d / c; return 1; }
+    double D = c * c - 4.0 * b * d;
+    if (D < 0.0) return 0;
+    D = sqrt(D);
+    ans[0] = 0.5 * (-c + D) / b; ans[1] = 0.5 * (-c - D) / b;
+    return 2;
+  }
+  const double kk = 1.0 / a, aa = b * kk, bb = c * kk, cc = d * kk, aa3 = aa / 3.0;
+  const double q = (aa * aa - 3.0 * bb) / 9.0;
+  const double r = (2.0 * aa * aa * aa - 9.0 * aa * bb + 27.0 * cc) / 54.0;
+  double help = r / sqrt(q * q * q);
+  if (fabs(help) > 1.0) help = (help < 0) ? -1.0 : 1.0;
+  const double phi = acos(help), p = sqrt(q);
+  ans[0] = -2.0 * p * cos(phi / 3.0) - aa3;
+  ans[1] = -2.0 * p * cos(phi / 3.0 + RAD_120) - aa3;
+  ans[2] = -2.0 * p * cos(phi / 3.0 - RAD_120) - aa3;
+  return 3;
+}
+static void principal_values(const double* v6, double* roots) {          /* Invariants::getPrincipalValues */
+  const int n = solve_cubic(roots, 1.0, -inv_I1(v6), inv_I2(v6), -inv_I3(v6));
+  for (int i = n; i < 3; i++) roots[i] = 0.0;
+}
+static double mazars_eq(int rank, const double* strain) {                /* DamageMaterial.cpp:618-642 */
+  double v6[6], princ[3], s = 0.0;
+  strain_v6(rank, strain, v6);
+  principal_values(v6, princ);
+  for (int i = 0; i < 3; i++) if (princ[i] > 0) s += princ[i] * princ[i];
+  return sqrt(s);
+}
+static void mazars_deriv(const fo_config* c, int rank, const double* strain, double* ret) {   /* :886-1032 */
+  const int n = (rank == 3) ? 6 : 4;
+  for (int i = 0; i < n; i++) ret[i] = 0.0;
+  if (rank == 3) {
+    double v[6], princ[3];
+    strain_v6(3, strain, v);
+    principal_values(v, princ);
+    const double I1 = inv_I1(v), I2 = inv_I2(v);
+    const double dI1[6] = { 1.0, 1.0, 1.0, 0.0, 0.0, 0.0 };
+    const double dI2[6] = { v[1] + v[2], v[2] + v[0], v[0] + v[1], -2. * v[3], -2. * v[4], -2. * v[5] };
+    const double dI3[6] = { v[1] * v[2] - v[4] * v[4], v[2] * v[0] - v[5] * v[5], v[0] * v[1] - v[3] * v[3],
+                            2.0 * (v[4] * v[5] - v[2] * v[3]), 2.0 * (v[5] * v[3] - v[0] * v[4]), 2.0 * (v[3] * v[4] - v[1] * v[5]) };
+    double epsBar = 0.0;
+    for (int i = 0; i < 3; i++) if (princ[i] > 0) epsBar += princ[i] * princ[i];
+    epsBar = sqrt(epsBar);
+    if (epsBar < 1.e-16) return;
+    for (int i = 0; i < 3; i++) {
+      const double vi = princ[i];
+      if (vi > 0) {
+        const double temp = 1.0 / (3.0 * vi * vi - 2.0 * I1 * vi + I2);
+        for (int k = 0; k < 6; k++) ret[k] += vi * (temp * (vi * vi * dI1[k] - vi * dI2[k] + dI3[k]));
+      }
+    }
+    for (int k = 0; k < 6; k++) ret[k] *= (1.0 / epsBar);
+    return;
+  }
+  const double exx = strain[0], eyy = strain[1], exy = 0.5 * strain[3];
+  const double exxMeyy = exx - eyy, exxPeyy = exx + eyy;
+  const double poi = c->poisson, poiD = poi / (poi - 1.0);
+  double d = sqrt(exxMeyy * exxMeyy + 4.0 * exy * exy);
+  double p0 = 0.5 * (exxPeyy + d), p1 = exxPeyy - p0, p2 = (c->state == FO_PLANE_STRESS) ? poiD * exxPeyy : 0.0;
+  p0 = p0 < 0. ? 0. : p0; p1 = p1 < 0. ? 0. : p1; p2 = p2 < 0. ? 0. : p2;
+  const double den = sqrt(p0 * p0 + p1 * p1 + p2 * p2);
+  if (den < 1e-08) return;
+  const double denInv = 1. / den;
+  const double dedprin0 = p0 * denInv, dedprin1 = p1 * denInv, dedprin2 = p2 * denInv;
+  if (d == 0.0) d = 1.0;
+  const double fac = 0.5 / d;
+  const double de1dexx = 0.5 + fac * exxMeyy, de1deyy = 1.0 - de1dexx, de1dexy = 2.0 * fac * exy;
+  const double de2dexx = de1deyy, de2deyy = de1dexx, de2dexy = -de1dexy;
+  const double de3dexx = poiD, de3deyy = de3dexx;
+  ret[0] = dedprin0 * de1dexx + dedprin1 * de2dexx + dedprin2 * de3dexx;
+  ret[1] = dedprin0 * de1deyy + dedprin1 * de2deyy + dedprin2 * de3deyy;
+  ret[3] = dedprin0 * de1dexy + dedprin1 * de2dexy;
+}
+
+/* test hook: Mazars equivalent strain, its derivative and the principal values of a STRAIN_COUNTS[rank] strain vector */
+int fo_mazars(const fo_config* cfg, int rank, const double* strain, double* eq, double* deriv, double* princ) {
+  if (rank != 2 && rank != 3) FAIL("rank %d", rank);
+  double v6[6];
+  strain_v6(rank, strain, v6);
+  principal_values(v6, princ);
+  *eq = mazars_eq(rank, strain);
+  mazars_deriv(cfg, rank, strain, deriv);
+  return 0;
+}
+
 /* GradientDamageModel::getMatrix_ (GradientDamageModel.cpp:368-588) with DamageMaterial::update (:356-440).
  * hist_pre / hist_new: kappa, negative when the loading flag is set (preHist_.eqveps / preHist_.loading). */
 static int assemble_gd(const fo_config* cfg, const double* coords, const int32_t* conn, int64_t el_begin, int64_t el_end,
@@ -864,6 +967,7 @@ static int assemble_gd(const fo_config* cfg, const double* coords, const int32_t
   shape_t sh;
   if (shape_init(&sh, cfg->shape)) return -1;
   if (cfg->material != FO_DAMAGE) FAIL("GradientDamage needs the Damage material");
+  if (cfg->eqv_strain != FO_EQV_ENERGY && cfg->eqv_strain != FO_EQV_MAZARS) FAIL("unexpected definition of equivalent strain!!! Restated here: Energy, Mazars");
   const int rank = sh.rank, nodeCount = sh.npe, ipCount = sh.nip;
   const int strCount = STRAIN_COUNTS[rank];
   const int dispCount = nodeCount * rank, eqvCount = nodeCount, ndofpn = rank + 1, srows = strCount + 1;
@@ -876,7 +980,7 @@ static int assemble_gd(const fo_config* cfg, const double* coords, const int32_t
   static __thread double bd[MAXSTR * MAXND], DB[MAXSTR * MAXND];
   static __thread double elemMat1[MAXND * MAXND], elemMat2[MAXND * MAXNPE], elemMat3[MAXNPE * MAXND], elemMat4[MAXNPE * MAXNPE];
   double xc[MAXNPE][3], ipWeights[MAXNIP], disp[MAXND], eqv[MAXNPE];
-  double stiff[MAXSTR * MAXSTR], stress[MAXSTR], strain[MAXSTR], d0e[MAXSTR];
+  double stiff[MAXSTR * MAXSTR], stress[MAXSTR], strain[MAXSTR], d0e[MAXSTR], deq[MAXSTR];
   double elemForce1[MAXND], elemForce2[MAXNPE];
   int64_t dispDofs[MAXND], eqvDofs[MAXNPE];
 
@@ -922,7 +1026,9 @@ static int assemble_gd(const fo_config* cfg, const double* coords, const int32_t
       hist_new[ipoint] = load ? -kappa : kappa;
 
       const double wip = ipWeights[ip];
-      matvec(strCount, stiff0, strain, d0e);                              /* stiff0 eps = dEpsBardEps (Energy), :700-705 */
+      matvec(strCount, stiff0, strain, d0e);                              /* stiff0 eps (:557); = dEpsBardEps for Energy, :700-705 */
+      if (cfg->eqv_strain == FO_EQV_MAZARS) mazars_deriv(cfg, rank, strain, deq);   /* getdEpsBardEps (:546) */
+      else for (int cc = 0; cc < strCount; cc++) deq[cc] = d0e[cc];
       if (mbuilder) {
         for (int cc = 0; cc < strCount; cc++) for (int j = 0; j < dispCount; j++) {      /* elemMat1 += wip bdt stiff bd */
           double s = 0.0;
@@ -936,7 +1042,7 @@ static int assemble_gd(const fo_config* cfg, const double* coords, const int32_t
         }
         for (int a = 0; a < eqvCount; a++) for (int j = 0; j < dispCount; j++) {         /* elemMat3 -= wip (N (x) dEpsBardEps) bd */
           double s = 0.0;
-          for (int cc = 0; cc < strCount; cc++) s += d0e[cc] * bd[cc * dispCount + j];
+          for (int cc = 0; cc < strCount; cc++) s += deq[cc] * bd[cc * dispCount + j];
           elemMat3[a * dispCount + j] -= wip * (Nip[a] * s);
         }
         if (load) {                                                        /* isLoading(ipoint): newHist_.loading, :549 */
@@ -953,7 +1059,8 @@ static int assemble_gd(const fo_config* cfg, const double* coords, const int32_t
         for (int i = 0; i < rank; i++) s += grads[ip][a][i] * grads[ip][b][i];
         elemMat4[a * eqvCount + b] += wip * (Nip[a] * Nip[b] + c * s);
       }
-      const double equiStrain = 0.5 * dotn(strCount, strain, d0e);         /* getEquiStrain, StrainEnergy */
+      const double equiStrain = (cfg->eqv_strain == FO_EQV_MAZARS) ? mazars_eq(rank, strain)
+                                                                    : 0.5 * dotn(strCount, strain, d0e);   /* getEquiStrain (:602-652) */
       for (int i = 0; i < dispCount; i++) {
         double s = 0.0;
         for (int cc = 0; cc < strCount; cc++) s += bd[cc * dispCount + i] * stress[cc];

@@ -56,6 +56,10 @@ enum { FO_HOOKE = 0, FO_AMOR = 1, FO_BOURDIN = 2, FO_MIEHE = 3, FO_DAMAGE = 4 };
 /* DamageMaterial softening laws restated (DamageMaterial.cpp:1044-1290) */
 enum { FO_SOFT_PERFECT = 0, FO_SOFT_LINEAR1 = 1, FO_SOFT_LINEAR2 = 2, FO_SOFT_EXPONENTIAL1 = 3, FO_SOFT_EXPONENTIAL2 = 4 };
 
+/* DamageMaterial equivalent strains restated: "Energy" (:644-649, :698-703) and "Mazars" (:618-642, :886-1032); the
+ * vonMises one returns a 6-vector for 2-D strains (:677-683) whose use in GradientDamageModel.cpp:548 is out of bounds */
+enum { FO_EQV_ENERGY = 0, FO_EQV_MAZARS = 1 };
+
 /* 2D problem state (HookeMaterial.cpp:92-103) */
 enum { FO_PLANE_STRAIN = 0, FO_PLANE_STRESS = 1 };
 
@@ -79,6 +83,7 @@ typedef struct {
   /* GradientDamage / Damage (DamageMaterial.cpp:157-268) */
   int    softening;
   double kappa_i, kappa_c, soft_alpha, soft_beta, length_scale;
+  int    eqv_strain;     /* FO_EQV_ENERGY / FO_EQV_MAZARS (DamageMaterial.cpp:275-308) */
 } fo_config;
 
 typedef struct {
@@ -119,6 +124,9 @@ int  fo_material_update(const fo_config* cfg, int rank, const double* strain, do
  * (row_ptr has nnode*ndofpn+1 entries).  Returns nnz. */
 int64_t fo_pattern(int nnode, int64_t nel, int npe, const int32_t* conn, int ndofpn, int rank,
                    int kind, int keep_off_diags, int64_t* row_ptr, int32_t* col_idx);
+
+/* Mazars equivalent strain of DamageMaterial (test hook): eq, d eq / d strain [STRAIN_COUNTS], principal values [3] */
+int fo_mazars(const fo_config* cfg, int rank, const double* strain, double* eq, double* deriv, double* princ);
 
 /* Element-serial assembly (LinearElasticityModel.cpp:297-430, PhaseFractureModel.cpp:502-751,
  * PhaseFractureExtModel.cpp:488-774, PhaseFractureExtItModel.cpp:518-797).

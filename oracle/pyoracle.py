@@ -22,6 +22,7 @@ HISTORY_MODELS = (PHASE_FRACTURE, MICRO_PHASE_FRACTURE, MICRO_EXT, MICRO_EXTIT, 
 # materials
 HOOKE, AMOR, BOURDIN, MIEHE, DAMAGE = range(5)
 SOFT_PERFECT, SOFT_LINEAR1, SOFT_LINEAR2, SOFT_EXPONENTIAL1, SOFT_EXPONENTIAL2 = range(5)
+EQV_ENERGY, EQV_MAZARS = 0, 1
 PLANE_STRAIN, PLANE_STRESS = 0, 1
 AT1, AT2, CZM_LINEAR, CZM_EXPONENTIAL, CZM_CORNELISSEN, CZM_HYPERBOLIC = range(6)
 PATTERN_FULL, PATTERN_WRITTEN = 0, 1
@@ -34,7 +35,7 @@ class Config(C.Structure):
                 ("gc", C.c_double), ("l0", C.c_double), ("sigma_t", C.c_double), ("beta", C.c_double),
                 ("keep_off_diags", C.c_int),
                 ("softening", C.c_int), ("kappa_i", C.c_double), ("kappa_c", C.c_double), ("soft_alpha", C.c_double),
-                ("soft_beta", C.c_double), ("length_scale", C.c_double)]
+                ("soft_beta", C.c_double), ("length_scale", C.c_double), ("eqv_strain", C.c_int)]
 
 
 class ShapeInfo(C.Structure):
@@ -76,6 +77,7 @@ def lib():
         L.fo_strain_table.argtypes = [C.c_int, C.c_int64, ip32, dp, C.c_int, C.c_int, dp, dp]
         L.fo_stress_table.argtypes = [C.POINTER(Config), C.c_int64, ip32, dp, C.c_int, dp, dp]
         L.fo_last_error.restype = C.c_char_p
+        L.fo_mazars.argtypes = [C.POINTER(Config), C.c_int, dp, dp, dp, dp]
         L.fo_arc_func.argtypes = [C.POINTER(Config), C.c_int, dp, C.c_int64, ip32, dp, dp, dp, dp]
         L.fo_eval_masters.argtypes = [dp, C.POINTER(Cons)]; L.fo_eval_masters.restype = None
         L.fo_eval_slaves.argtypes = [dp, C.POINTER(Cons)]; L.fo_eval_slaves.restype = None
@@ -135,9 +137,9 @@ def ndof_per_node(model, rank):
 
 def make_config(shape, model, material, state=PLANE_STRAIN, young=210e3, poisson=0.3, frac_type=AT2,
                 gc=2.7, l0=0.015, sigma_t=0.0, beta=6500.0, keep_off_diags=0, softening=0, kappa_i=0.0, kappa_c=0.0,
-                soft_alpha=0.0, soft_beta=0.0, length_scale=0.0):
+                soft_alpha=0.0, soft_beta=0.0, length_scale=0.0, eqv_strain=0):
     return Config(shape, model, material, state, young, poisson, frac_type, gc, l0, sigma_t, beta,
-                  int(keep_off_diags), softening, kappa_i, kappa_c, soft_alpha, soft_beta, length_scale)
+                  int(keep_off_diags), softening, kappa_i, kappa_c, soft_alpha, soft_beta, length_scale, eqv_strain)
 
 
 def psi0(cfg):
@@ -158,6 +160,15 @@ def material_update(cfg, rank, strain, gphi=1.0):
                                 _p(stiff, C.c_double), C.byref(psi), _p(sp, C.c_double)):
         raise ValueError(lib().fo_last_error().decode())
     return stress, stiff, psi.value, sp
+
+
+def mazars(cfg, rank, strain):
+    """(eq, d eq / d strain, principal values) as DamageMaterial computes them."""
+    strain = np.ascontiguousarray(strain, dtype=np.float64)
+    eq = C.c_double(); d = np.zeros(strain.size); pr = np.zeros(3)
+    if lib().fo_mazars(C.byref(cfg), rank, _p(strain, C.c_double), C.byref(eq), _p(d, C.c_double), _p(pr, C.c_double)):
+        raise ValueError(lib().fo_last_error().decode())
+    return eq.value, d, pr
 
 
 def keep_code(cfg):

@@ -248,8 +248,9 @@ def damage_law(soft, Ki, Kc, al, be, K):
     return (0.0 if K < Ki else 1 - Ki / K * ex), Ki / K ** 2 * ex + Ki / K * ex / (Kc - Ki)
 
 
-def element_gd(x, N, dN, w, u, eqv, kap0, load0, D0, law, c, want_K=True):
-    """returns K1, K2, K3, K4, f1, f2, kappa, loading.  law = (soft, Ki, Kc, alpha, beta)."""
+def element_gd(x, N, dN, w, u, eqv, kap0, load0, D0, law, c, want_K=True, mazars=None):
+    """returns K1, K2, K3, K4, f1, f2, kappa, loading.  law = (soft, Ki, Kc, alpha, beta); mazars = (nu, plane_stress)
+    for eqvStrain = Mazars, None for Energy."""
     npe, rank = x.shape
     nd = rank * npe
     K1 = np.zeros((nd, nd)); K2 = np.zeros((nd, npe)); K3 = np.zeros((npe, nd)); K4 = np.zeros((npe, npe))
@@ -272,11 +273,83 @@ def element_gd(x, N, dN, w, u, eqv, kap0, load0, D0, law, c, want_K=True):
         om, dom = damage_law(*law, kap[ip])
         D = (1 - om) * D0
         K1 += wip * B.T @ D @ B
-        K3 -= wip * np.outer(Nip, (D0 @ eps) @ B)
+        deq = D0 @ eps if mazars is None else mazars_deriv(eps, *mazars)
+        K3 -= wip * np.outer(Nip, deq @ B)
         if ld[ip]:
             K2 -= wip * dom * B.T @ D0 @ np.outer(eps, Nip)
         K4 += wip * (np.outer(Nip, Nip) + c * g @ g.T)
         f1 += wip * B.T @ (D @ eps)
-        f2 -= wip * 0.5 * eps @ D0 @ eps * Nip
+        f2 -= wip * (0.5 * eps @ D0 @ eps if mazars is None else mazars_eq(eps)) * Nip
     f2 += K4 @ eqv
     return K1, K2, K3, K4, f1, f2, kap, ld
+
+
+# ---- Mazars equivalent strain as DamageMaterial computes it (DamageMaterial.cpp:618-642, :886-1032): principal values
+# from the trigonometric solution of the characteristic cubic (MathUtils.cpp:112-182) with the reference's truncated
+# PI = 3.14159265 (Constants.cpp:13) -- written independently of the C oracle, same published formulas ----
+REF_PI = 3.14159265
+
+
+def strain_tensor_v6(strain):
+    v = np.zeros(6)
+    v[:3] = strain[:3]; v[3] = 0.5 * strain[3]
+    if strain.size == 6:
+        v[4] = 0.5 * strain[4]; v[5] = 0.5 * strain[5]
+    return v
+
+
+def principal_values_ref(v):
+    I1 = v[0] + v[1] + v[2]
+    I2 = v[0] * v[1] + v[1] * v[2] + v[2] * v[0] - (v[3] ** 2 + v[4] ** 2 + v[5] ** 2)
+    I3 = v[0] * v[1] * v[2] + 2 * v[3] * v[4] * v[5] - v[0] * v[4] ** 2 - v[1] * v[5] ** 2 - v[2] * v[3] ** 2
+    aa, bb, cc = -I1, I2, -I3
+    q = (aa * aa - 3 * bb) / 9.0
+    r = (2 * aa ** 3 - 9 * aa * bb + 27 * cc) / 54.0
+    with np.errstate(all="ignore"):
+        h = r / np.sqrt(q * q * q)
+        if abs(h) > 1.0:
+            h = -1.0 if h < 0 else 1.0
+        phi = np.arccos(h); p = np.sqrt(q)
+        rad = 0.6666666666666667 * REF_PI
+        roots = np.array([-2 * p * np.cos(phi / 3) - aa / 3, -2 * p * np.cos(phi / 3 + rad) - aa / 3,
+                          -2 * p * np.cos(phi / 3 - rad) - aa / 3])
+    return roots, I1, I2
+
+
+def mazars_eq(strain):
+    pr, _, _ = principal_values_ref(strain_tensor_v6(strain))
+    return np.sqrt(sum(x * x for x in pr if x > 0))
+
+
+def mazars_deriv(strain, nu, plane_stress):
+    n = strain.size
+    ret = np.zeros(n)
+    if n == 6:
+        v = strain_tensor_v6(strain)
+        pr, I1, I2 = principal_values_ref(v)
+        dI1 = np.array([1.0, 1, 1, 0, 0, 0])
+        dI2 = np.array([v[1] + v[2], v[2] + v[0], v[0] + v[1], -2 * v[3], -2 * v[4], -2 * v[5]])
+        dI3 = np.array([v[1] * v[2] - v[4] ** 2, v[2] * v[0] - v[5] ** 2, v[0] * v[1] - v[3] ** 2,
+                        2 * (v[4] * v[5] - v[2] * v[3]), 2 * (v[5] * v[3] - v[0] * v[4]), 2 * (v[3] * v[4] - v[1] * v[5])])
+        bar = np.sqrt(sum(x * x for x in pr if x > 0))
+        if bar < 1e-16:
+            return ret
+        for x in pr:
+            if x > 0:
+                ret += x * (x * x * dI1 - x * dI2 + dI3) / (3 * x * x - 2 * I1 * x + I2)
+        return ret / bar
+    exx, eyy, exy = strain[0], strain[1], 0.5 * strain[3]
+    d = np.sqrt((exx - eyy) ** 2 + 4 * exy * exy)
+    poiD = nu / (nu - 1.0)
+    p0 = 0.5 * (exx + eyy + d); p1 = exx + eyy - p0; p2 = poiD * (exx + eyy) if plane_stress else 0.0
+    p0, p1, p2 = max(p0, 0.0), max(p1, 0.0), max(p2, 0.0)
+    den = np.sqrt(p0 * p0 + p1 * p1 + p2 * p2)
+    if den < 1e-8:
+        return ret
+    if d == 0.0:
+        d = 1.0
+    a = 0.5 + 0.5 / d * (exx - eyy); b = 1.0 - a; c = 2.0 * 0.5 / d * exy
+    ret[0] = (p0 * a + p1 * b + p2 * poiD) / den
+    ret[1] = (p0 * b + p1 * a + p2 * poiD) / den
+    ret[3] = (p0 * c - p1 * c) / den
+    return ret

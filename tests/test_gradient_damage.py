@@ -20,9 +20,9 @@ LAWS = {po.SOFT_PERFECT: dict(kappa_i=1.0e-3),
         po.SOFT_EXPONENTIAL2: dict(kappa_i=1.0e-3, kappa_c=6.0e-3)}
 
 
-def gd_config(shape, soft, state2d=po.PLANE_STRAIN, c=0.02):
+def gd_config(shape, soft, state2d=po.PLANE_STRAIN, c=0.02, eqv=po.EQV_ENERGY):
     return po.make_config(shape, po.GRADIENT_DAMAGE, po.DAMAGE, state=state2d, young=E, poisson=NU, softening=soft,
-                          length_scale=c, **LAWS[soft])
+                          length_scale=c, eqv_strain=eqv, **LAWS[soft])
 
 
 def gd_state(coords, rank, seed=3):
@@ -119,21 +119,26 @@ def test_uniaxial_element_closed_form():
         assert (np.abs(csr_dense(rp, ci, out3["K"])[np.ix_(ux, pd)]).max() > 0) == (hist[0] < 0)
 
 
-@pytest.mark.parametrize("shape,soft", [(po.QUAD4_G2, po.SOFT_EXPONENTIAL2), (po.QUAD4_G2, po.SOFT_LINEAR1),
-                                        (po.TRI3_G1, po.SOFT_PERFECT), (po.HEX8_G2, po.SOFT_EXPONENTIAL1),
-                                        (po.QUAD8_G3, po.SOFT_LINEAR2), (po.TRI6_G3, po.SOFT_EXPONENTIAL2)])
-def test_oracle_vs_numpy_restatement(shape, soft):
+@pytest.mark.parametrize("shape,soft,eqv,state2d", [
+    (po.QUAD4_G2, po.SOFT_EXPONENTIAL2, po.EQV_ENERGY, po.PLANE_STRAIN), (po.QUAD4_G2, po.SOFT_LINEAR1, po.EQV_ENERGY, po.PLANE_STRAIN),
+    (po.TRI3_G1, po.SOFT_PERFECT, po.EQV_ENERGY, po.PLANE_STRAIN), (po.HEX8_G2, po.SOFT_EXPONENTIAL1, po.EQV_ENERGY, po.PLANE_STRAIN),
+    (po.QUAD8_G3, po.SOFT_LINEAR2, po.EQV_ENERGY, po.PLANE_STRAIN), (po.TRI6_G3, po.SOFT_EXPONENTIAL2, po.EQV_ENERGY, po.PLANE_STRAIN),
+    (po.TRI3_G1, po.SOFT_EXPONENTIAL1, po.EQV_MAZARS, po.PLANE_STRESS),      # the material of the reference's tests/sm03
+    (po.QUAD4_G2, po.SOFT_EXPONENTIAL2, po.EQV_MAZARS, po.PLANE_STRAIN), (po.HEX8_G2, po.SOFT_LINEAR1, po.EQV_MAZARS, po.PLANE_STRAIN),
+    (po.QUAD8_G3, po.SOFT_EXPONENTIAL1, po.EQV_MAZARS, po.PLANE_STRESS)])
+def test_oracle_vs_numpy_restatement(shape, soft, eqv, state2d):
     rank, npe, nip, _ = po.shape_info(shape)
     coords, conn = GRID[shape]()
     coords = meshgen.distort(coords, conn, 0.12 if npe in (3, 4, 8) and shape != po.QUAD8_G3 else 0.05)
     nn = coords.shape[0]; nd = rank + 1
-    cfg = gd_config(shape, soft)
+    cfg = gd_config(shape, soft, state2d, eqv=eqv)
     rp, ci = po.pattern(nn, conn, nd, rank)
     st = gd_state(coords, rank)
     H0 = gd_history(conn.shape[0] * nip)
     out = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=H0, want_strain=True)
     N, dN, w = po.shape_tables(shape)
-    D0 = np_ref.hooke(rank, 0, E, NU)
+    D0 = np_ref.hooke(rank, state2d, E, NU)
+    maz = (NU, state2d == po.PLANE_STRESS) if eqv == po.EQV_MAZARS else None
     kw = LAWS[soft]
     law = (soft, kw["kappa_i"], kw.get("kappa_c", 0.0), kw.get("soft_alpha", 0.0), kw.get("soft_beta", 0.0))
     ndof = nn * nd
@@ -143,7 +148,7 @@ def test_oracle_vs_numpy_restatement(shape, soft):
         ud = np.array([[n * nd + i for i in range(rank)] for n in c]).ravel(); pd = c * nd + rank
         h = H0[e * nip:(e + 1) * nip]
         K1, K2, K3, K4, f1, f2, kap, ld = np_ref.element_gd(coords[c], N, dN, w, S[c, :rank].ravel(), S[c, rank],
-                                                            np.abs(h), (h < 0).astype(int), D0, law, 0.02)
+                                                            np.abs(h), (h < 0).astype(int), D0, law, 0.02, mazars=maz)
         K[np.ix_(ud, ud)] += K1; K[np.ix_(pd, pd)] += K4
         K[np.ix_(ud, pd)] += K2; K[np.ix_(pd, ud)] += K3
         f[ud] += f1; f[pd] += f2; Hn[e * nip:(e + 1) * nip] = np.where(ld == 1, -kap, kap)
@@ -176,6 +181,49 @@ def test_tangent_is_the_derivative_of_f_int_when_loading():
         assert np.allclose(fd, K[:, j], rtol=1e-5, atol=1e-6 * np.abs(K[:, j]).max() + 1e-9), j
 
 
+def test_mazars_principal_values_and_derivative():
+    """The reference takes the principal strains from the trigonometric solution of the characteristic cubic with
+    PI = 3.14159265 (Constants.cpp:13): they agree with numpy's eigenvalues to ~1e-9 of the strain scale, not to
+    rounding.  d eq / d strain: plane strain and the normal components in 3-D are the derivative of eq (central
+    differences); the 3-D shear entries are derivatives with respect to the TENSOR shear components (Invariants.cpp
+    works on 0.5 gamma), i.e. twice the derivative with respect to the engineering shear strain the B matrix produces."""
+    rng = np.random.default_rng(4)
+    cfg = gd_config(po.QUAD4_G2, po.SOFT_PERFECT, po.PLANE_STRAIN, eqv=po.EQV_MAZARS)
+    cfgs = gd_config(po.QUAD4_G2, po.SOFT_PERFECT, po.PLANE_STRESS, eqv=po.EQV_MAZARS)
+    for k in range(200):
+        e = rng.uniform(-1e-3, 1e-3, 4); e[2] = 0.0
+        if k % 4 == 0:
+            e[:2] = np.abs(e[:2])
+        eq, d, pr = po.mazars(cfg, 2, e)
+        T = np.array([[e[0], e[3] / 2, 0], [e[3] / 2, e[1], 0], [0, 0, 0]])
+        assert np.allclose(np.sort(pr), np.linalg.eigvalsh(T), rtol=0, atol=2e-8 * np.abs(e).max())
+        assert abs(eq - np_ref.mazars_eq(e)) <= 1e-13 * np.abs(e).max()
+        assert np.allclose(d, np_ref.mazars_deriv(e, NU, False), rtol=1e-12, atol=1e-14)
+        assert np.allclose(po.mazars(cfgs, 2, e)[1], np_ref.mazars_deriv(e, NU, True), rtol=1e-12, atol=1e-14)
+        ev = np.linalg.eigvalsh(T)
+        if min(abs(ev[0]), abs(ev[2])) > 1e-5 and eq > 1e-5:                 # away from the kinks of <.>
+            h = 1e-8
+            for j in (0, 1, 3):
+                ep = e.copy(); ep[j] += h; em = e.copy(); em[j] -= h
+                fd = (po.mazars(cfg, 2, ep)[0] - po.mazars(cfg, 2, em)[0]) / (2 * h)
+                assert abs(fd - d[j]) < 2e-6, (k, j, fd, d[j])
+    for k in range(200):
+        e = rng.uniform(-1e-3, 1e-3, 6)
+        eq, d, pr = po.mazars(cfg, 3, e)
+        T = np.array([[e[0], e[3] / 2, e[5] / 2], [e[3] / 2, e[1], e[4] / 2], [e[5] / 2, e[4] / 2, e[2]]])
+        ev = np.linalg.eigvalsh(T)
+        assert np.allclose(np.sort(pr), ev, rtol=0, atol=2e-8 * np.abs(e).max())
+        assert abs(eq - np_ref.mazars_eq(e)) <= 1e-13 * np.abs(e).max()
+        assert np.allclose(d, np_ref.mazars_deriv(e, NU, False), rtol=1e-11, atol=1e-13)
+        if np.abs(ev).min() > 2e-5 and min(ev[1] - ev[0], ev[2] - ev[1]) > 1e-4 and eq > 1e-5:
+            h = 1e-8
+            for j in range(6):
+                ep = e.copy(); ep[j] += h; em = e.copy(); em[j] -= h
+                fd = (po.mazars(cfg, 3, ep)[0] - po.mazars(cfg, 3, em)[0]) / (2 * h)
+                assert abs((2.0 if j >= 3 else 1.0) * fd - d[j]) < 5e-5, (k, j, fd, d[j])
+    assert po.mazars(cfg, 2, np.zeros(4))[0] == 0.0 and np.all(po.mazars(cfg, 3, np.zeros(6))[1] == 0.0)   # NaN roots count as "not positive"
+
+
 def test_refusals():
     coords, conn = meshgen.grid_quad4(1, 1)
     rp, ci = po.pattern(4, conn, 3, 2)
@@ -191,13 +239,17 @@ GPU_MESH = {po.TRI3_G1: lambda: meshgen.grid_tri3(9, 7), po.QUAD4_G2: lambda: me
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,soft,state2d", [
-    (po.QUAD4_G2, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN), (po.QUAD4_G2, po.SOFT_LINEAR1, po.PLANE_STRESS),
-    (po.QUAD4_G2, po.SOFT_PERFECT, po.PLANE_STRAIN), (po.TRI3_G1, po.SOFT_LINEAR2, po.PLANE_STRAIN),
-    (po.TRI3_G1, po.SOFT_EXPONENTIAL1, po.PLANE_STRESS), (po.HEX8_G2, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN),
-    (po.HEX8_G2, po.SOFT_EXPONENTIAL1, po.PLANE_STRAIN), (po.TRI6_G3, po.SOFT_LINEAR1, po.PLANE_STRAIN),
-    (po.QUAD8_G3, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN), (po.HEX20_G2, po.SOFT_LINEAR2, po.PLANE_STRAIN)])
-def test_gpu_gradient_damage_parity(shape, soft, state2d):
+@pytest.mark.parametrize("shape,soft,state2d,eqv", [
+    (po.QUAD4_G2, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN, 0), (po.QUAD4_G2, po.SOFT_LINEAR1, po.PLANE_STRESS, 0),
+    (po.QUAD4_G2, po.SOFT_PERFECT, po.PLANE_STRAIN, 0), (po.TRI3_G1, po.SOFT_LINEAR2, po.PLANE_STRAIN, 0),
+    (po.TRI3_G1, po.SOFT_EXPONENTIAL1, po.PLANE_STRESS, 0), (po.HEX8_G2, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN, 0),
+    (po.HEX8_G2, po.SOFT_EXPONENTIAL1, po.PLANE_STRAIN, 0), (po.TRI6_G3, po.SOFT_LINEAR1, po.PLANE_STRAIN, 0),
+    (po.QUAD8_G3, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN, 0), (po.HEX20_G2, po.SOFT_LINEAR2, po.PLANE_STRAIN, 0),
+    (po.TRI3_G1, po.SOFT_EXPONENTIAL1, po.PLANE_STRESS, 1),                   # the material of the reference's tests/sm03
+    (po.QUAD4_G2, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN, 1), (po.QUAD4_G2, po.SOFT_LINEAR1, po.PLANE_STRESS, 1),
+    (po.HEX8_G2, po.SOFT_LINEAR1, po.PLANE_STRAIN, 1), (po.QUAD8_G3, po.SOFT_EXPONENTIAL1, po.PLANE_STRESS, 1),
+    (po.TRI6_G3, po.SOFT_PERFECT, po.PLANE_STRAIN, 1), (po.HEX20_G2, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN, 1)])
+def test_gpu_gradient_damage_parity(shape, soft, state2d, eqv):
     """K + f pass, commit, K + f pass on the unchanged state (the f == 0 branch), then a force-only pass, each against
     the oracle carrying its own history the same way."""
     import torch
@@ -207,11 +259,11 @@ def test_gpu_gradient_damage_parity(shape, soft, state2d):
     rank, npe, nip, _ = po.shape_info(shape)
     coords, conn = GPU_MESH[shape]()
     coords = meshgen.distort(coords, conn, 0.15 if shape in (po.TRI3_G1, po.QUAD4_G2, po.HEX8_G2) else 0.06, 1)
-    cfg = gd_config(shape, soft, state2d)
+    cfg = gd_config(shape, soft, state2d, eqv=eqv)
     st = gd_state(coords, rank)
     H0 = gd_history(conn.shape[0] * nip)
     asm = capi.Assembler(shape, capi.GRADIENT_DAMAGE, capi.DAMAGE, coords, conn, state=state2d, young=E, poisson=NU,
-                         softening=soft, length_scale=0.02, **LAWS[soft])
+                         softening=soft, length_scale=0.02, eqv_strain=eqv, **LAWS[soft])
     rp, ci = asm.pattern()
     rpo, cio = po.pattern(coords.shape[0], conn, rank + 1, rank, po.PATTERN_FULL, po.keep_code(cfg))
     assert np.array_equal(rp, rpo) and np.array_equal(ci, cio)
@@ -255,3 +307,6 @@ def test_gpu_gradient_damage_refusals():
     with pytest.raises(capi.FaError):
         capi.Assembler(capi.QUAD4_G2, capi.GRADIENT_DAMAGE, capi.DAMAGE, coords, conn, young=E, poisson=NU,
                        softening=capi.SOFT_LINEAR1, kappa_i=2e-3, kappa_c=1e-3)
+    with pytest.raises(capi.FaError):                                         # vonMises (2) and anything else
+        capi.Assembler(capi.QUAD4_G2, capi.GRADIENT_DAMAGE, capi.DAMAGE, coords, conn, young=E, poisson=NU,
+                       softening=capi.SOFT_PERFECT, kappa_i=1e-3, eqv_strain=2)

@@ -203,3 +203,74 @@ def test_micro_ext_models_through_take_action():
     ok, _, f = case.take_action("GET_INT_VECTOR", state=st, state0=st0, state00=st00, iter_count=0)
     r = po.assemble(cfg, coords, conn, rp, ci, st, state00=ext, want_K=False)
     assert ok and np.abs(f - r["f"]).max() < 1e-12 * np.abs(f).max()
+
+
+def _read_mesh(text):
+    """nodes / elements / element groups of a falcon .mesh file (ids as written, 1-based)."""
+    import re
+    sec = lambda tag: re.search(r"<%s[^>]*>(.*?)</%s>" % (tag, tag), text, re.S).group(1)
+    nodes = {int(t.split()[0]): [float(v) for v in t.split()[1:]] for t in sec("Nodes").split(";") if t.strip()}
+    elems = {int(t.split()[0]): [int(v) for v in t.split()[1:]] for t in sec("Elements").split(";") if t.strip()}
+    groups = {m.group(1): [int(v) for v in re.findall(r"\d+", m.group(2))]
+              for m in re.finditer(r'<ElementGroup name="([^"]+)">(.*?)</ElementGroup>', text, re.S)}
+    return nodes, elems, groups
+
+
+def test_sm03_errors_mirror_the_reference():
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sm03")
+    pro = open(os.path.join(g, "model.pro")).read(); mesh = open(os.path.join(g, "problem.mesh")).read()
+    with pytest.raises(hostapi.HostError, match="material type is not a damage material"):
+        hostapi.Case(pro.replace('"Damage"', '"Hooke"'), mesh)
+    pf = pro.replace('"GradientDamage"', '"PhaseFracture"').replace('elements = "bulk";', 'elements = "bulk"; fractureType = "at2";')
+    with pytest.raises(hostapi.HostError, match="not a PhaseFractureMaterial"):
+        hostapi.Case(pf, mesh)
+
+
+@pytest.mark.gpu
+def test_sm03_gradient_damage_through_take_action():
+    """The reference's tests/sm03 (mesh and material as shipped): INIT, GET_MATRIX0, COMMIT, GET_MATRIX0 on the committed
+    state (the exact f == 0 branch of DamageMaterial::update), GET_INT_VECTOR -- against the oracle on the same mesh."""
+    from oracle import pyoracle as po
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sm03")
+    pro = open(os.path.join(g, "model.pro")).read(); mesh = open(os.path.join(g, "problem.mesh")).read()
+    with pytest.raises(hostapi.HostError, match="unexpected definition of softening law"):
+        hostapi.Case(pro.replace('"exponential1"', '"cubic"'), mesh)
+    with pytest.raises(hostapi.HostError, match="vonMises"):
+        hostapi.Case(pro.replace('"Mazars"', '"vonMises"'), mesh)
+    case = hostapi.Case(pro, mesh)
+    assert case.model_type == "GradientDamage"
+    nodes, elems, groups = _read_mesh(mesh)
+    ids = sorted(nodes)
+    assert ids == list(range(1, len(ids) + 1))
+    coords = np.array([nodes[i][:2] for i in ids])
+    conn = np.array([[n - 1 for n in elems[e]] for e in groups["bulk"]], dtype=np.int32)
+    nn = len(ids)
+    assert case.ndof == 3 * nn and case.dof(1, "eqv") == 2 and case.dof(2, "dx") == 3
+    assert case.take_action("INIT")[0] is True                           # Triangle3: nothing to constrain (:710-714)
+    rp, ci = case.pattern()
+    rpo, cio = po.pattern(nn, conn, 3, 2, po.PATTERN_FULL, 1)
+    assert np.array_equal(rp, rpo) and np.array_equal(ci, cio)
+    cfg = po.make_config(po.TRI3_G1, po.GRADIENT_DAMAGE, po.DAMAGE, state=po.PLANE_STRESS, young=40.e3, poisson=0.2,
+                         softening=po.SOFT_EXPONENTIAL1, kappa_i=0.000075, soft_alpha=0.92, soft_beta=300., length_scale=1.0,
+                         eqv_strain=po.EQV_MAZARS)
+    # a bending-like displacement field of the 500 x 100 beam with strains around kappaI, nonlocal strain on both sides of it
+    x, y = coords[:, 0], coords[:, 1]
+    st = np.zeros(3 * nn)
+    st[0::3] = 2e-4 * (y - 50.0) * np.sin(np.pi * x / 500.0) * 0.02
+    st[1::3] = -3e-3 * np.sin(np.pi * x / 500.0)
+    st[2::3] = 1.2e-4 * np.exp(-((x - 250.0) / 60.0) ** 2) * (1.0 - y / 130.0) + 1e-5
+    ok, K, f = case.take_action("GET_MATRIX0", state=st)
+    r1 = po.assemble(cfg, coords, conn, rp, ci, st)
+    assert ok and (r1["hist_new"] < 0).sum() > 20 and (r1["hist_new"] > 0).sum() > 20          # loading and elastic points
+    scale = np.abs(r1["K"]).max()
+    assert np.abs(K - r1["K"]).max() < 1e-12 * scale and np.abs(f - r1["f"]).max() < 1e-12 * np.abs(r1["f"]).max()
+    assert case.take_action("COMMIT")[0] and case.take_action("CHECK_COMMIT")[0]
+    ok, K2, f2 = case.take_action("GET_MATRIX0", state=st)
+    r2 = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=r1["hist_new"])
+    assert np.array_equal(r2["hist_new"], r1["hist_new"])                                       # f == 0: kappa and flag kept
+    assert ok and np.abs(K2 - r2["K"]).max() < 1e-12 * scale and np.abs(f2 - r2["f"]).max() < 1e-12 * np.abs(r2["f"]).max()
+    st3 = st.copy(); st3[2::3] *= 0.7                                     # unloading everywhere
+    ok, _, f3 = case.take_action("GET_INT_VECTOR", state=st3)
+    r3 = po.assemble(cfg, coords, conn, rp, ci, st3, hist_pre=r1["hist_new"], want_K=False)
+    assert ok and np.abs(f3 - r3["f"]).max() < 1e-12 * np.abs(r3["f"]).max()
+    assert case.take_action("setStepSize", step=0.5, step0=0.25)[0] is False
