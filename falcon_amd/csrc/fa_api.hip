@@ -812,7 +812,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   }
   // ---- node patches (patch kernel) ----
   fa::PatchSet ps;
-  if (rows_ok && nel > 0 && c->fam != fa::FAM_PF_MIEHE && dbg.use_patch) {               // experimental, opt-in
+  if (rows_ok && nel > 0 && c->fam != fa::FAM_PF_MIEHE && dbg.use_patch && !gd) {               // experimental, opt-in
     int cap = (rank == 2) ? 6144 : 16384;                       // doubles of LDS for the CSR image
     if (dbg.patch_lds > 0) cap = std::max(64, dbg.patch_lds);
     const size_t lim = 160 * 1024;
@@ -888,7 +888,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   fa::TileSet tsK, tsF;
   {
     const bool shape_ok = p->shape == FA_QUAD4_G2 || p->shape == FA_TRI3_G1;
-    const bool wanted = dbg.emat >= 0 ? dbg.emat != 0 : false;
+    const bool wanted = (dbg.emat >= 0 ? dbg.emat != 0 : false) && !gd;   // (no GradientDamage instantiations of the opt-in kernel)
     if (shape_ok && wanted && P.canon && nel > 0) {
       const bool keepK = P.keep2 || P.keep3;
       const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE && p->model != FA_GRADIENT_DAMAGE;

@@ -34,7 +34,7 @@ struct CoopSlot {
   IpMat<SH, FAM, KEEP> m[SH::NIP];
 };
 
-template <class SH, int FAM, bool WANT_K, bool KEEP>
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP = SpecRuntime>
 __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, S = SH::S, STR = SH::STR, kBlock = 256;
   constexpr int EPB = coop_epb(RANK, NPE, NIP);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
       for (int i = 0; i < RANK; i++) L.gphi[ip][i] = gphi[i];
     }
     IpMat<SH, FAM, KEEP> m;
-    ip_material<SH, FAM, KEEP>(P, ipoint, eps, pf, pf0, pfX, H0, true, m, err_acc);
+    ip_material<SH, FAM, KEEP, SP>(P, ipoint, eps, pf, pf0, pfX, H0, true, m, err_acc);
     L.m[ip] = m;
   }
   __syncthreads();
@@ -319,7 +319,10 @@ __global__ __launch_bounds__(256) void assemble_coop(const Params P) {
 
 template <class SH, int FAM, bool WANT_K, bool KEEP>
 static int launch_coop_one(const Params& P, int grid, hipStream_t st) {
-  hipLaunchKernelGGL((assemble_coop<SH, FAM, WANT_K, KEEP>), dim3(grid), dim3(256), 0, st, P);
+  if constexpr (FAM == FAM_PF_ISO) {                   // GradientDamage: its own instantiation (SpecGD)
+    if (P.model == 7) { hipLaunchKernelGGL((assemble_coop<SH, FAM, WANT_K, KEEP, SpecGD<SpecRuntime>>), dim3(grid), dim3(256), 0, st, P); return (int)hipGetLastError(); }
+  }
+  hipLaunchKernelGGL((assemble_coop<SH, FAM, WANT_K, KEEP, SpecRuntime>), dim3(grid), dim3(256), 0, st, P);
   return (int)hipGetLastError();
 }
 

@@ -890,6 +890,7 @@ static int launch_fvec_shape(const Params& P, int fam, int grid, void* stream) {
   if (fam == FAM_LE) return launch_fvec_one<SH, FAM_LE, SpecFixed<0, 0, 0>>(P, grid, st);
   if (fam == FAM_PF_ISO) {
     if (P.model == 1 && P.ptype == 0 && P.material == 1) return launch_fvec_one<SH, FAM_PF_ISO, SpecFixed<1, 0, 1>>(P, grid, st);
+    if (P.model == 7) return launch_fvec_one<SH, FAM_PF_ISO, SpecGD<SpecCanon>>(P, grid, st);
     return launch_fvec_one<SH, FAM_PF_ISO, SpecCanon>(P, grid, st);
   }
   if (fam == FAM_PF_MIEHE) return launch_fvec_one<SH, FAM_PF_MIEHE, SpecCanon>(P, grid, st);

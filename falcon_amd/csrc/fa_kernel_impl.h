@@ -47,6 +47,8 @@ struct Shape {
 // (uniform branches); SpecFixed folds model / degradation exponent / material into the code and promises the
 // canonical dof numbering (the row kernels' precondition), which removes every uniform branch from the Gauss-point loop.
 struct SpecRuntime {
+  static constexpr bool gd = false;                    // GradientDamage has kernels of its own (SpecGD): its constitutive
+                                                       // branch (exp, acos, cos) costs every runtime-model kernel registers
   static __device__ __forceinline__ int model(const Params& P) { return P.model; }
   static __device__ __forceinline__ int ptype(const Params& P) { return P.ptype; }
   static __device__ __forceinline__ int material(const Params& P) { return P.material; }
@@ -57,10 +59,18 @@ struct SpecCanon : SpecRuntime {                       // runtime model, canonic
 };
 template <int MODEL, int PTYPE, int MAT>
 struct SpecFixed {
+  static constexpr bool gd = false;
   static __device__ __forceinline__ constexpr int model(const Params&) { return MODEL; }
   static __device__ __forceinline__ constexpr int ptype(const Params&) { return PTYPE; }
   static __device__ __forceinline__ constexpr int material(const Params&) { return MAT; }
   static __device__ __forceinline__ constexpr bool custom_dofs(const Params&) { return false; }
+};
+
+// GradientDamage (model 7) on top of a runtime spec: the only instantiations that contain DamageMaterial's update
+template <class BASE>
+struct SpecGD : BASE {
+  static constexpr bool gd = true;
+  static __device__ __forceinline__ constexpr int model(const Params&) { return 7; }
 };
 
 template <int I, int N>
@@ -584,8 +594,8 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
         return;
       }
     }
-    if constexpr (FAM == FAM_PF_ISO) {
-      if (SP::model(P) == 7) {
+    if constexpr (FAM == FAM_PF_ISO && SP::gd) {
+      {
         // GradientDamageModel.cpp:500-560 with DamageMaterial::update (DamageMaterial.cpp:356-440), eqvStrain = Energy:
         // pf is the nonlocal equivalent strain at the point (strain_(strCount, ipoint), :524), H0 the committed kappa
         // with the loading flag in its sign bit.
@@ -1588,7 +1598,7 @@ __device__ __forceinline__ int64_t find_col(const Params& P, int64_t row, int64_
   return -1;
 }
 
-template <class SH, int FAM, bool WANT_K, bool KEEP>
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP>
 __global__ __launch_bounds__(SH::BLOCK) void assemble_generic(const Params P) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, kBlock = SH::BLOCK;
   constexpr bool PF = (FAM != FAM_LE);
@@ -1604,7 +1614,7 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_generic(const Params P) {
 #pragma unroll
     for (int b = 0; b < NPE; b++) cn[b] = P.conn[e * NPE + b];
     RowBlock<SH, WANT_K, PF, KEEP> R;
-    compute_rowblock<SH, FAM, WANT_K, KEEP>(P, e, la, cn, true, R, err_acc);
+    compute_rowblock<SH, FAM, WANT_K, KEEP, SP>(P, e, la, cn, true, R, err_acc);
     auto dof = [&](int node, int i) -> int64_t {
       return P.node_dofs ? P.node_dofs[(int64_t)node * NDOF + i] : (int64_t)node * NDOF + i;
     };
@@ -1667,6 +1677,7 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
       if constexpr (FAM == FAM_LE) go(SpecFixed<0, 0, 0>{});
       else if constexpr (FAM == FAM_PF_ISO) {
         if (P.model == 1 && P.ptype == 0 && P.material == 1) go(SpecFixed<1, 0, 1>{});
+        else if (P.model == 7) go(SpecGD<SpecCanon>{});
         else go(SpecCanon{});
       } else {
         if (P.model == 1 && P.ptype == 0) go(SpecFixed<1, 0, 3>{});
@@ -1684,13 +1695,17 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
     if constexpr (FAM == FAM_LE) go(SpecFixed<0, 0, 0>{});
     else if constexpr (FAM == FAM_PF_ISO) {
       if (P.model == 1 && P.ptype == 0 && P.material == 1) go(SpecFixed<1, 0, 1>{});
+      else if (P.model == 7) go(SpecGD<SpecCanon>{});
       else go(SpecCanon{});
     } else {
       if (P.model == 1 && P.ptype == 0) go(SpecFixed<1, 0, 3>{});
       else go(SpecCanon{});
     }
   } else {
-    hipLaunchKernelGGL((assemble_generic<SH, FAM, WANT_K, KEEP>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
+    if constexpr (FAM == FAM_PF_ISO) {
+      if (P.model == 7) { hipLaunchKernelGGL((assemble_generic<SH, FAM, WANT_K, KEEP, SpecGD<SpecRuntime>>), dim3(grid), dim3(SH::BLOCK), 0, st, P); return (int)hipGetLastError(); }
+    }
+    hipLaunchKernelGGL((assemble_generic<SH, FAM, WANT_K, KEEP, SpecRuntime>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
   }
   return (int)hipGetLastError();
 }

@@ -1046,6 +1046,10 @@ static int launch_tiles_shape(const Params& P, int fam, bool want_K, bool keep, 
   if (fam == FAM_LE)
     return want_K ? launch_tiles_one<SH, FAM_LE, true, false, SpecFixed<0, 0, 0>>(P, grid, st)
                   : launch_tiles_one<SH, FAM_LE, false, false, SpecFixed<0, 0, 0>>(P, grid, st);
+  if (fam == FAM_PF_ISO && P.model == 7) {              // GradientDamage: all four blocks
+    if (!want_K) return launch_tiles_one<SH, FAM_PF_ISO, false, false, SpecGD<SpecCanon>>(P, grid, st);
+    return keep ? launch_tiles_one<SH, FAM_PF_ISO, true, true, SpecGD<SpecCanon>>(P, grid, st) : -1000;
+  }
   if (fam == FAM_PF_ISO) {
     if (!want_K) return launch_tiles_one<SH, FAM_PF_ISO, false, false, SpecCanon>(P, grid, st);
     return keep ? launch_tiles_one<SH, FAM_PF_ISO, true, true, SpecCanon>(P, grid, st)
