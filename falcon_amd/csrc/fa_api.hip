@@ -60,6 +60,7 @@ struct DebugOptions {
   int  tile_sort = -1;    // FA_TILE_SORT=0|1: owned nodes of a tile in Morton order | ascending node id
   int  tile_fu = -1;      // FA_TILE_FU=0|1: 3-D elastic GET_MATRIX0 passes take f_int from the pair lanes (K u) off / on
   int  tile_big = -1;     // FA_TILE_BIG=0|1: two 512-thread workgroups per CU | one of 1024 threads
+  int  tile_cell = -1;    // FA_TILE_CELL=abc: tiles are boxes of a x b x c nodes (3-D shapes; 0: Morton cells; -1: per-shape default)
   int  emat = -1;         // FA_EMAT=0|1: element-matrix tile kernel (Quad4 / Triangle3) off / on
   int  fvec = -1;         // FA_FVEC=0|1: force-vector kernel (GET_INT_VECTOR passes of Quad4 / Triangle3) off / on
   int  persist = -1;      // FA_PERSIST=0|1: persistent LDS-DMA kernels off / on
@@ -80,7 +81,7 @@ struct DebugOptions {
     o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_fu = geti("FA_TILE_FU", -1); o.tile_sort = geti("FA_TILE_SORT", -1); o.tile_split = geti("FA_TILE_SPLIT", -1);
     o.emat = geti("FA_EMAT", -1); o.emat_lds = geti("FA_EMAT_LDS", 0); o.emat_lpe = geti("FA_EMAT_LPE", 0);
     o.emat_lpe_f = geti("FA_EMAT_LPE_F", 0); o.fvec = geti("FA_FVEC", -1); o.fvec_blk = geti("FA_FVEC_BLK", 0); o.fvec_atomic = geti("FA_FVEC_ATOMIC", -1);
-    o.persist = geti("FA_PERSIST", -1);
+    o.persist = geti("FA_PERSIST", -1); o.tile_cell = geti("FA_TILE_CELL", -1);
     o.no_pair = getenv("FA_NO_PAIR") != nullptr; o.pair_3d = getenv("FA_PAIR_3D") != nullptr;
     o.pad_rec = geti("FA_PAD_REC", 1); o.use_patch = getenv("FA_USE_PATCH") != nullptr;
     o.patch_lds = geti("FA_PATCH_LDS", 0); o.verbose = getenv("FA_VERBOSE") != nullptr;
@@ -858,6 +859,13 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       P.tile_fu = (topt.group > 1 && (dbg.tile_fu >= 0 ? dbg.tile_fu != 0 : true)) ? 1 : 0;   // capability; decided per call
       if (topt.group > 1 && !topt.sym_all) return fail(FA_ERR_UNSUPPORTED, "FA_TILE_SYM=0 / row order is not available for the grouped pair lanes of the 3-D elastic kernels");
       P.tile_split = topt.split > 0 ? 1 : 0;
+      {
+        // Hex8: boxes of 3 x 3 x 3 nodes bring 4 x 4 x 4 = 64 elements = 512 (element, Gauss point) lanes, one full round of the
+        // workgroup, at 2.4 evaluations per point; the Morton cut (4 x 4 x 2 does not fit the LDS budget) gave 21.7 nodes / 57
+        // elements at 2.7 (cfg4 at 128^3: 5.45 -> 5.25 ms, GET_INT_VECTOR 2.30 -> 2.07 ms)
+        const int cellc = dbg.tile_cell >= 0 ? dbg.tile_cell : (p->shape == FA_HEX8_G2 ? 333 : 0);
+        if (rank == 3 && cellc >= 111) { topt.cell[0] = cellc / 100; topt.cell[1] = (cellc / 10) % 10; topt.cell[2] = cellc % 10; }
+      }
       c->tile_path = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
                                      nb_ptr.data(), nb.data(), recw, fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0),
                                      big ? fa::kTileLdsBig : fa::kTileLds, P.tile_block, row_order, ts, topt);

@@ -1050,6 +1050,12 @@ static int launch_tiles_shape(const Params& P, int fam, bool want_K, bool keep, 
     if (!want_K) return launch_tiles_one<SH, FAM_PF_ISO, false, false, SpecGD<SpecCanon>>(P, grid, st);
     return keep ? launch_tiles_one<SH, FAM_PF_ISO, true, true, SpecGD<SpecCanon>>(P, grid, st) : -1000;
   }
+  if (fam == FAM_PF_ISO && P.model == 1 && P.ptype == 0 && P.material == 1) {   // PhaseFracture, AT1 / AT2, AmorPhase folded in (cfg4)
+    using SPF = SpecFixed<1, 0, 1>;
+    if (!want_K) return launch_tiles_one<SH, FAM_PF_ISO, false, false, SPF>(P, grid, st);
+    return keep ? launch_tiles_one<SH, FAM_PF_ISO, true, true, SPF>(P, grid, st)
+                : launch_tiles_one<SH, FAM_PF_ISO, true, false, SPF>(P, grid, st);
+  }
   if (fam == FAM_PF_ISO) {
     if (!want_K) return launch_tiles_one<SH, FAM_PF_ISO, false, false, SpecCanon>(P, grid, st);
     return keep ? launch_tiles_one<SH, FAM_PF_ISO, true, true, SpecCanon>(P, grid, st)

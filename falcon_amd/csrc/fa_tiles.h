@@ -61,6 +61,9 @@ struct TileOpts {
                             //   diagonal);  first element word
                             // entries of a lane: nb words  ib | position of a in b's row << 16 | position of b in a's row
                             // << 24, then per element 2 words  slot | la << 16  and  lb_0 | lb_1 << 8 | lb_2 << 16 | lb_3 << 24
+  int cell[3] = { 0, 0, 0 };// cell[0] > 0: tiles are boxes of cell[0] x cell[1] x cell[2] grid-quantised nodes (walked along a
+                            // Morton curve of the boxes) instead of power-of-two Morton cells: 3 x 3 x 3 nodes of a Hex8 mesh
+                            // bring 4 x 4 x 4 = 64 elements, i.e. exactly 512 (element, Gauss point) lanes
   int fvec = 0;             // > 0: force-vector mode (fa_emat_impl.h, assemble_fvec): no element slots, no pair lanes; per
                             // element the slot ranks of its nodes, per owned node its valence (<= fvec)
 };

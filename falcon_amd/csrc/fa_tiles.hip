@@ -71,7 +71,8 @@ struct Cutter {                                        // greedy cut of the sort
                     counts->push_back((int32_t)n_pairs); counts->push_back((int32_t)n_ents); }
       cur++; n_own = n_all = n_el = n_pairs = n_ents = 0;
     };
-    const int64_t min_own = (L >= 1) ? (int64_t(1) << (L - 1)) : 1;
+    const int64_t min_own = opts.cell[0] > 0 ? std::max<int64_t>(1, (int64_t)opts.cell[0] * std::max(opts.cell[1], 1) * std::max(opts.cell[2], 1) / 2)
+                                             : ((L >= 1) ? (int64_t(1) << (L - 1)) : 1);
     for (int64_t i = 0; i < upto; i++) {
       const int32_t n = order[(size_t)i];
       const uint64_t cell = (L >= 63) ? 0 : (key[(size_t)i] >> L);
@@ -139,6 +140,17 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
         const double v = std::floor((coords[n * rank + d] - lo[d]) / h + 0.5);
         q[d] = (uint64_t)std::min<double>(std::max(v, 0.0), (double)qmax);
       }
+      if (opts.cell[0] > 0) {                           // box cells: Morton code of the box, then the node's place in it
+        uint64_t cq[3] = { 0, 0, 0 }, lq = 0, mul = 1;
+        for (int d = 0; d < rank; d++) {
+          const uint64_t cd = (uint64_t)std::max(opts.cell[d], 1);
+          cq[d] = q[d] / cd; lq += (q[d] % cd) * mul; mul *= cd;
+        }
+        const uint64_t mc = (rank == 3) ? (spread3(cq[0]) | (spread3(cq[1]) << 1) | (spread3(cq[2]) << 2))
+                                        : (spread2(cq[0]) | (spread2(cq[1]) << 1));
+        code[(size_t)n] = (mc << 8) | (lq & 0xFFu);
+        continue;
+      }
       code[(size_t)n] = (rank == 3) ? (spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2))
                                     : (spread2(q[0]) | (spread2(q[1]) << 1));
     }
@@ -161,6 +173,8 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
     std::vector<int32_t> cs;
     double best = 1e300;
     const int cand[] = { 63, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2 };
+    if (opts.cell[0] > 0) L = 8;                        // box cells: the low 8 bits number the nodes of a box
+    else
     for (int tryL : cand) {
       if (!C.cut(tryL, sample, starts, &cs, by_limit)) return false;
       double el = 0.0, own = 0.0;
