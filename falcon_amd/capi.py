@@ -63,11 +63,25 @@ EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_
 _lib = None
 
 
+def _torch_first():
+    """PyTorch's wheel carries a HIP runtime of its own (torch/lib/libamdhip64.so) next to the /opt/rocm one this library
+    links: the two share a process only when torch's has initialised the GPU first (the other order leaves torch with
+    "No HIP GPUs are available").  Callers that hand over torch tensors therefore get torch initialised before the
+    library's first HIP call; a process without torch is not affected."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise FaError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _torch_first()
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.fa_create.argtypes = [C.POINTER(Problem), C.POINTER(vp)]

@@ -66,6 +66,7 @@ struct DebugOptions {
   int  persist = -1;      // FA_PERSIST=0|1: persistent LDS-DMA kernels off / on
   int  fvec_atomic = -1;  // FA_FVEC_ATOMIC=0|1: force-vector kernel with ordered per-element rows | one atomic row per node
   int  fvec_blk = 0;      // FA_FVEC_BLK=192|256|320: its workgroup size = elements per tile (0: default)
+  int  fvec_cell = -1;    // FA_FVEC_CELL=abc: Hex8 force-vector tiles are boxes of a x b x c nodes (0 / -1: Morton cells)
   int  emat_lds = 0;      // FA_EMAT_LDS=n: LDS bytes of one element-matrix tile (0: default)
   int  emat_lpe = 0;      // FA_EMAT_LPE=1|2: lanes per element of its GET_MATRIX0 passes (0: default)
   int  emat_lpe_f = 0;    // FA_EMAT_LPE_F=1|2: the same for GET_INT_VECTOR passes
@@ -80,7 +81,7 @@ struct DebugOptions {
     auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_fu = geti("FA_TILE_FU", -1); o.tile_sort = geti("FA_TILE_SORT", -1); o.tile_split = geti("FA_TILE_SPLIT", -1);
     o.emat = geti("FA_EMAT", -1); o.emat_lds = geti("FA_EMAT_LDS", 0); o.emat_lpe = geti("FA_EMAT_LPE", 0);
-    o.emat_lpe_f = geti("FA_EMAT_LPE_F", 0); o.fvec = geti("FA_FVEC", -1); o.fvec_blk = geti("FA_FVEC_BLK", 0); o.fvec_atomic = geti("FA_FVEC_ATOMIC", -1);
+    o.emat_lpe_f = geti("FA_EMAT_LPE_F", 0); o.fvec = geti("FA_FVEC", -1); o.fvec_blk = geti("FA_FVEC_BLK", 0); o.fvec_cell = geti("FA_FVEC_CELL", -1); o.fvec_atomic = geti("FA_FVEC_ATOMIC", -1);
     o.persist = geti("FA_PERSIST", -1); o.tile_cell = geti("FA_TILE_CELL", -1);
     o.no_pair = getenv("FA_NO_PAIR") != nullptr; o.pair_3d = getenv("FA_PAIR_3D") != nullptr;
     o.pad_rec = geti("FA_PAD_REC", 1); o.use_patch = getenv("FA_USE_PATCH") != nullptr;
@@ -922,18 +923,25 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
                 c->ematF.ok ? "ok" : "not built", tsF.ntile, tsF.ntile ? (double)nnode / tsF.ntile : 0.0, tsF.lds_bytes, tsF.point_redundancy, c->ematF.lpe);
     }
   }
-  // ---- force-vector kernel (GET_INT_VECTOR passes of Quad4 / Triangle3): needs the canonical dof numbering only ----
+  // ---- force-vector kernel (GET_INT_VECTOR passes of Quad4 / Triangle3 / Hex8): needs the canonical dof numbering only ----
   fa::TileSet tsV;
   {
-    const bool shape_ok = p->shape == FA_QUAD4_G2 || p->shape == FA_TRI3_G1;
+    const bool shape_ok = p->shape == FA_QUAD4_G2 || p->shape == FA_TRI3_G1 || p->shape == FA_HEX8_G2;
     const bool wanted = dbg.fvec >= 0 ? dbg.fvec != 0 : true;
     if (shape_ok && wanted && canonical_dofs && c->ndof == nnode * nd && nel > 0 && maxval <= 8) {
       const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE && p->model != FA_GRADIENT_DAMAGE;
       const int nodw = fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0);
-      c->fvec.block = (dbg.fvec_blk == 128 || dbg.fvec_blk == 192 || dbg.fvec_blk == 256 || dbg.fvec_blk == 320) ? dbg.fvec_blk : 192;
+      // Hex8: 128 threads = the 125 elements around a Morton cell of 4 x 4 x 4 nodes (cfg4 at 128^3: 0.945 ms; 192 threads with
+      // boxes of 5 x 5 x 4 nodes 1.01 ms, with the Morton cut 1.37 ms; the tile kernel's Gauss-point lanes 2.06 ms)
+      c->fvec.block = (dbg.fvec_blk == 128 || dbg.fvec_blk == 192 || dbg.fvec_blk == 256 || dbg.fvec_blk == 320) ? dbg.fvec_blk : (rank == 3 ? 128 : 192);
       fa::TileOpts o;
       o.no_tab = true; o.no_f_image = true; o.fvec = maxval; o.own_doubles = (maxval * nd) | 1; o.own_doubles_alt = nd; o.max_el = c->fvec.block;
-      o.conn_pad4 = true; o.max_all = 2 * c->fvec.block;
+      o.conn_pad4 = npe <= 4; o.max_all = 2 * c->fvec.block;
+      if (rank == 3) {                                  // Hex8: more nodes than elements in a tile; box cells as for the tile kernel
+        o.max_all = 0;
+        const int cellc = dbg.fvec_cell >= 0 ? dbg.fvec_cell : 0;
+        if (cellc >= 111) { o.cell[0] = cellc / 100; o.cell[1] = (cellc / 10) % 10; o.cell[2] = cellc % 10; }
+      }
       o.sort_local = dbg.tile_sort >= 0 ? dbg.tile_sort != 0 : true;
       c->fvec.ok = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
                                    nb_ptr.data(), nb.data(), 0, nodw, 48 * 1024, c->fvec.block, false, tsV, o);

@@ -503,7 +503,8 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
   constexpr bool PF = (FAM != FAM_LE);
   constexpr int NDOF = PF ? RANK + 1 : RANK;
   constexpr int NODW = tile_node_doubles(RANK, PF);
-  static_assert(NPE <= 4, "one byte of the rank word per element node");
+  static_assert(NPE <= 8, "one byte of the rank words per element node");
+  constexpr int EW = (NPE + 3) / 4;                    // rank words per element
   extern __shared__ double smem[];
   __shared__ double sErr[BLK / 64];
 
@@ -532,8 +533,14 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
   uint8_t* sVal = reinterpret_cast<uint8_t*>(sConn + n_el * CS);
 
   // ---- phase 0: stage (the first pass's element words and history values are requested before the barrier) ----
-  uint32_t ew0 = 0, es0 = 0;
-  if (tid < n_el) { ew0 = (uint32_t)P.telems[elem_off + tid]; es0 = P.eslot[elem_off + tid]; }
+  uint32_t ew0 = 0, es0[EW];
+#pragma unroll
+  for (int q = 0; q < EW; q++) es0[q] = 0;
+  if (tid < n_el) {
+    ew0 = (uint32_t)P.telems[elem_off + tid];
+#pragma unroll
+    for (int q = 0; q < EW; q++) es0[q] = P.eslot[(int64_t)(elem_off + tid) * EW + q];
+  }
   for (int i = tid; i < n_all; i += BLK) {
     const int64_t n = P.tnodes[node_off + i];
     if (i < n_own) { sNode[i] = (int)n; sVal[i] = (uint8_t)P.nval[node_off + i]; }
@@ -568,9 +575,13 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
   const const_dptr tabD = tabN + NIP * NPE;
   const const_dptr tabW = tabN + NIP * NPE * (1 + RANK);
   for (int t = tid; t < n_el; t += BLK) {
-    uint32_t ew = ew0, es = es0;
+    uint32_t ew = ew0, es[EW];
+#pragma unroll
+    for (int q = 0; q < EW; q++) es[q] = es0[q];
     if (t != tid) {                                    // later passes (tiles of more than BLK elements)
-      ew = (uint32_t)P.telems[elem_off + t]; es = P.eslot[elem_off + t];
+      ew = (uint32_t)P.telems[elem_off + t];
+#pragma unroll
+      for (int q = 0; q < EW; q++) es[q] = P.eslot[(int64_t)(elem_off + t) * EW + q];
       if (hist_model) {
 #pragma unroll
         for (int k = 0; k < NIP; k++) H0v[k] = P.hist_pre[(int64_t)(ew & 0x7FFFFFFFu) * NIP + k];
@@ -584,6 +595,126 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
     for (int a = 0; a < NPE; a++) li[a] = (int)lc[a];
     EmatAcc<SH, FAM, false, false> A;
     A.zero();
+    if constexpr (RANK == 3) {
+      // 3-D shapes (Hex8): no gathered element data and no nodal gradients in registers.  One pass over the nodes gives
+      // J = sum x_a (x) dN_a, F = sum u_a (x) dN_a and sum phi_a dN_a in reference space; strain = sym(F J^-1),
+      // grad phi = J^-T (.), and the rows are f1_a = dN_a . T with T = w J^-1 sigma, f2_a = w N_a cf + dN_a . G with
+      // G = c2 w J^-1 grad phi -- the same expressions as the Gauss-point lanes of the tile kernel (fa_tile_impl.h).
+      constexpr int S = SH::S, STR = SH::STR;
+#pragma unroll 1
+      for (int ip = 0; ip < NIP; ip++) {
+        asm volatile("" ::: "memory");
+        double J[RANK][RANK], Fm[RANK][RANK], gref[RANK], pf = 0.0, pf0 = 0.0, pfX = 0.0;
+#pragma unroll
+        for (int i = 0; i < RANK; i++) {
+          gref[i] = 0.0;
+#pragma unroll
+          for (int k = 0; k < RANK; k++) { J[i][k] = 0.0; Fm[i][k] = 0.0; }
+        }
+#pragma unroll
+        for (int a = 0; a < NPE; a++) {
+          const double* nd = sNod + li[a] * NODW;
+#pragma unroll
+          for (int k = 0; k < RANK; k++) {
+            const double dn = tabD[(ip * NPE + a) * RANK + k];
+#pragma unroll
+            for (int i = 0; i < RANK; i++) { J[i][k] += nd[i] * dn; Fm[i][k] += nd[RANK + i] * dn; }
+            if constexpr (PF) gref[k] += nd[2 * RANK] * dn;
+          }
+          if constexpr (PF) {
+            const double Na = tabN[ip * NPE + a];
+            pf += Na * nd[2 * RANK];
+            if (SP::model(P) == 2 || SP::model(P) == 3) { pf0 += Na * sExt[2 * li[a]]; pfX += Na * sExt[2 * li[a] + 1]; }
+            else if (SP::model(P) == 5 || SP::model(P) == 6) pfX += Na * sExt[2 * li[a] + 1];
+          }
+        }
+        double inv[RANK][RANK];
+        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+        const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+        const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+        const double rd = 1.0 / det;
+        inv[0][0] = c00 * rd;
+        inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
+        inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * rd;
+        inv[1][0] = c01 * rd;
+        inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * rd;
+        inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rd;
+        inv[2][0] = c02 * rd;
+        inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
+        inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
+        const double w = tabW[ip] * det;
+        double Hm[RANK][RANK], eps[S], gphi[RANK];
+#pragma unroll
+        for (int i = 0; i < RANK; i++)
+#pragma unroll
+          for (int j = 0; j < RANK; j++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < RANK; k++) acc += Fm[i][k] * inv[k][j];
+            Hm[i][j] = acc;
+          }
+        eps[0] = Hm[0][0]; eps[1] = Hm[1][1]; eps[2] = Hm[2][2];           // ShapeUtils.cpp:114-145: xx yy zz xy yz zx
+        eps[3] = Hm[0][1] + Hm[1][0]; eps[4] = Hm[1][2] + Hm[2][1]; eps[5] = Hm[2][0] + Hm[0][2];
+#pragma unroll
+        for (int i = 0; i < RANK; i++) {
+          double acc = 0.0;
+#pragma unroll
+          for (int k = 0; k < RANK; k++) acc += gref[k] * inv[k][i];
+          gphi[i] = acc;
+        }
+        const int64_t ipoint = e * NIP + ip;
+        if (P.strain != nullptr && write) {
+          double* sc = P.strain + ipoint * (PF ? STR + 1 : STR);
+#pragma unroll
+          for (int c = 0; c < S; c++) sc[c] = eps[c];
+        }
+        double H0 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NIP; k++) if (k == ip) H0 = H0v[k];
+        IpMat<SH, FAM, false> m;
+        ip_material<SH, FAM, false, SP>(P, ipoint, eps, pf, pf0, pfX, H0, write, m, err_acc);
+        double sm[RANK][RANK], T[RANK][RANK], G[RANK];
+        sm[0][0] = m.sig[0]; sm[1][1] = m.sig[1]; sm[2][2] = m.sig[2];
+        sm[0][1] = sm[1][0] = m.sig[3]; sm[1][2] = sm[2][1] = m.sig[4]; sm[0][2] = sm[2][0] = m.sig[5];
+#pragma unroll
+        for (int k = 0; k < RANK; k++) {
+#pragma unroll
+          for (int i = 0; i < RANK; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < RANK; j++) acc += inv[k][j] * sm[j][i];
+            T[k][i] = w * acc;
+          }
+          if constexpr (PF) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < RANK; j++) acc += inv[k][j] * gphi[j];
+            G[k] = (P.c2 * w) * acc;
+          }
+        }
+        const double wcf = PF ? w * m.cf : 0.0;
+#pragma unroll
+        for (int a = 0; a < NPE; a++) {
+          double dn[RANK];
+#pragma unroll
+          for (int k = 0; k < RANK; k++) dn[k] = tabD[(ip * NPE + a) * RANK + k];
+#pragma unroll
+          for (int i = 0; i < RANK; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < RANK; k++) acc += dn[k] * T[k][i];
+            A.fu[a][i] += acc;
+          }
+          if constexpr (PF) {
+            double acc = wcf * tabN[ip * NPE + a];
+#pragma unroll
+            for (int k = 0; k < RANK; k++) acc += dn[k] * G[k];
+            A.fp[a] += acc;
+          }
+        }
+      }
+    } else
 #pragma unroll 1
     for (int ip = 0; ip < NIP; ip++) {
       // the nodal values are re-read from LDS for every point: 40 registers less than keeping them across the loop
@@ -624,7 +755,7 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
           for (int i = 0; i < RANK; i++) atomicAdd(&dst[i], A.fu[a][i]);
           if constexpr (PF) atomicAdd(&dst[RANK], A.fp[a]);
         } else {
-          double* dst = sBuf + li[a] * SB + (int)((es >> (8 * a)) & 0xFFu) * NDOF;
+          double* dst = sBuf + li[a] * SB + (int)((es[a >> 2] >> (8 * (a & 3))) & 0xFFu) * NDOF;
 #pragma unroll
           for (int i = 0; i < RANK; i++) dst[i] = A.fu[a][i];
           if constexpr (PF) dst[RANK] = A.fp[a];
@@ -872,11 +1003,13 @@ static int launch_fvec_one(const Params& P, int grid, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(blk), shmem, st, P);
     return (int)hipGetLastError();
   };
-  if (P.persistent) {
-    if (P.tile_block == 192) return go(assemble_fvec_p<SH, FAM, SP, 192>, 192);
-    if (P.tile_block == 256) return go(assemble_fvec_p<SH, FAM, SP, 256>, 256);
-    return -1000;
-  }
+  if constexpr (SH::NPE <= 4) {
+    if (P.persistent) {
+      if (P.tile_block == 192) return go(assemble_fvec_p<SH, FAM, SP, 192>, 192);
+      if (P.tile_block == 256) return go(assemble_fvec_p<SH, FAM, SP, 256>, 256);
+      return -1000;
+    }
+  } else if (P.persistent) return -1000;
   if (P.tile_block == 320) return go(assemble_fvec<SH, FAM, SP, 320>, 320);
   if (P.tile_block == 192) return go(assemble_fvec<SH, FAM, SP, 192>, 192);
   if (P.tile_block == 256) return go(assemble_fvec<SH, FAM, SP, 256>, 256);

@@ -193,6 +193,7 @@ int launch_emat_quad4_g2(const Params&, int fam, bool want_K, bool keep, int gri
 int launch_emat_tri3_g1 (const Params&, int fam, bool want_K, bool keep, int grid, void* stream);
 int launch_fvec_quad4_g2(const Params&, int fam, int grid, void* stream);
 int launch_fvec_tri3_g1 (const Params&, int fam, int grid, void* stream);
+int launch_fvec_hex8_g2 (const Params&, int fam, int grid, void* stream);
 
 // getStress_ table kernels, one per space dimension (fa_kernels_quad4.hip / fa_kernels_hex8.hip)
 int launch_stress_table_2d(const Params&, int npe, int nip, int plane_stress, double* table, double* weights, void* stream);

@@ -10,4 +10,5 @@ int launch_emat_tri3_g1(const Params& P, int fam, bool want_K, bool keep, int gr
 }
 int launch_fvec_quad4_g2(const Params& P, int fam, int grid, void* stream) { return launch_fvec_shape<Shape<2, 4, 4>>(P, fam, grid, stream); }
 int launch_fvec_tri3_g1(const Params& P, int fam, int grid, void* stream) { return launch_fvec_shape<Shape<2, 3, 1>>(P, fam, grid, stream); }
+int launch_fvec_hex8_g2(const Params& P, int fam, int grid, void* stream) { return launch_fvec_shape<Shape<3, 8, 8>>(P, fam, grid, stream); }
 }  // namespace fa

@@ -3,6 +3,7 @@
 
 namespace fa {
 int launch_hex8_g2(const Params& P, int fam, bool want_K, bool keep, int path, int grid, void* stream) {
+  if (path == PATH_FVEC) return launch_fvec_hex8_g2(P, fam, grid, stream);
   if (path == PATH_TILES) return launch_tiles_shape<Shape<3,8,8>>(P, fam, want_K, keep, grid, stream);
   return launch_shape<Shape<3,8,8>>(P, fam, want_K, keep, path, grid, stream);
 }

@@ -17,8 +17,8 @@ struct TileSet {
   std::vector<uint32_t> tpairs;          // 4 words per pair lane: owned index | row position << 16 | elements << 24, entry offset,
                                          // mirror (second owned index | its row position << 16 | bit 31) or 0, pad
   std::vector<uint32_t> tents;           // one word per (pair, shared element)
-  std::vector<uint32_t> eslot;           // fvec mode: per tile element, byte a = rank of the element among the incident
-                                         // elements of its local node a (element-ascending)
+  std::vector<uint32_t> eslot;           // fvec mode: per tile element (npe + 3) / 4 words, byte a = rank of the element among the
+                                         // incident elements of its local node a (element-ascending)
   std::vector<uint32_t> nval;            // fvec mode: per tile node, the number of incident elements (owned nodes only)
   int max_all = 0, max_el = 0, max_own = 0;   // largest node / element / owned-node count of a tile
   int conn_stride = 0;                   // entries of tconn per tile element (npe, or 4 when padded)

@@ -220,7 +220,8 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
   if (split_mode) split_pairs.resize((size_t)ntile); else T.tpairs.assign((size_t)o_pair[ntile] * 4, 0);
   if (!(opts.group > 1 && order_mode == 0 && opts.sym_all)) T.tents.assign((size_t)o_ent[ntile], 0);
   T.point_redundancy = (double)o_el[ntile] / (double)nel;
-  if (opts.fvec > 0) { T.eslot.assign((size_t)o_el[ntile], 0); T.nval.assign((size_t)o_node[ntile], 0); }
+  const int esw = (npe + 3) / 4;                        // fvec mode: rank words per element (one byte per element node)
+  if (opts.fvec > 0) { if (npe > 8) return false; T.eslot.assign((size_t)o_el[ntile] * esw, 0); T.nval.assign((size_t)o_node[ntile], 0); }
 
   // ---- fill ----
   par_for(ntile, [&](int64_t tb, int64_t te) {
@@ -269,7 +270,7 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
       }
       if (opts.fvec > 0) {
         // force-vector mode: rank of every tile element in the (element-ascending) incident lists of its nodes
-        uint32_t* es = T.eslot.data() + o_el[t];
+        uint32_t* es = T.eslot.data() + o_el[t] * esw;
         uint32_t* nv = T.nval.data() + o_node[t];
         for (int ia = 0; ia < n_own; ia++) {
           const int32_t a = own[ia];
@@ -277,7 +278,7 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
           for (int32_t u = n2e_ptr[a]; u < n2e_ptr[a + 1]; u++) {
             const int32_t el = n2e_ent[u] / npe, la = n2e_ent[u] - el * npe;
             const size_t slot = (size_t)(std::lower_bound(els.begin(), els.end(), el) - els.begin());
-            es[slot] |= (uint32_t)(u - n2e_ptr[a]) << (8 * la);
+            es[slot * esw + (la >> 2)] |= (uint32_t)(u - n2e_ptr[a]) << (8 * (la & 3));
           }
         }
         ti[6] = 0;

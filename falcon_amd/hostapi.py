@@ -18,6 +18,8 @@ class HostError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
+        from falcon_amd.capi import _torch_first
+        _torch_first()                       # see capi._torch_first: torch's HIP runtime has to come up first
         L = C.CDLL(LIB_PATH)
         vp, dp = C.c_void_p, C.POINTER(C.c_double)
         L.fh_create.argtypes = [C.c_char_p, C.c_char_p]; L.fh_create.restype = vp
