@@ -79,7 +79,7 @@ enum {
   FA_STORE_STRAIN = 2,  /* also materialise the strain_ cache (PhaseFractureModel.cpp:651,678) */
   FA_FORCE_GENERIC = 4, /* testing: use the generic atomic-scatter kernel even for a canonical pattern */
   FA_DETERMINISTIC = 8  /* bitwise run-to-run reproducible K/f: every entry summed in ascending element order (the ordered
-                           row kernel; the force-vector kernel for GET_INT_VECTOR passes of Quad4 / Triangle3).  Exists for
+                           row kernel; the force-vector kernel for GET_INT_VECTOR passes of Quad4 / Triangle3 / Hex8).  Exists for
                            Triangle3/Gauss1, Quad4 and Hex8 on the canonical node-major pattern only: on every other
                            context (higher-order shapes, a custom dof map or pattern) the call is refused with
                            FA_ERR_UNSUPPORTED -- those kernels add f_int (and, for non-canonical patterns, K) with

@@ -2,6 +2,8 @@
 oracle to 1e-12 through the C ABI, for the shapes it is the default of, with shuffled node numbering, the Ext state
 arrays, off-diagonal blocks, += semantics, GET_INT_VECTOR passes, and bitwise repeatability of K (every entry has one
 writer and a fixed summation order)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -84,6 +86,20 @@ def test_tile_kernel_parity_on_many_tiles(case):
     assert (f2 - f).abs().max().item() < 1e-12 * fmax
     assert (K3 - 2.0 - K).abs().max().item() < 1e-12 * kmax and (f3 - 1.0 - f).abs().max().item() < 1e-12 * fmax
     assert (f4 - f).abs().max().item() < 1e-12 * fmax
+    # the GET_INT_VECTOR pass (Hex8: the force-vector kernel) rewrites newHist_ as well, and repeats bit for bit
+    if hist is not None:
+        assert np.abs(asm.get_history(1) - ref["hist_new"]).max() < 1e-12 * max(1.0, np.abs(ref["hist_new"]).max())
+    if shape == capi.HEX8_G2 and os.environ.get("FA_FVEC") != "0":   # (FA_FVEC=0: f4 came from the tile kernel's LDS atomics)
+        f5 = torch.zeros_like(f)
+        asm.assemble(t(st), None, f5, flags=capi.OVERWRITE | capi.DETERMINISTIC, **args)
+        assert torch.equal(f4, f5)
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_hex8_force_only_through_the_tile_kernel(case, monkeypatch):
+    """FA_FVEC=0: what a Hex8 mesh with a node of more than 8 elements gets for GET_INT_VECTOR passes."""
+    monkeypatch.setenv("FA_FVEC", "0")
+    test_tile_kernel_parity_on_many_tiles(case)
 
 
 def test_lodi_sums_on_the_device():
