@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: one full-size block per GPU | the one mesh divided")
     ap.add_argument("--k-halo", default="additive", choices=["additive", "reduce"],
                     help="N > 1: leave the subdomain matrices additive (Jive's distributed representation) | send the interface rows of K to the lower rank")
+    ap.add_argument("--no-f-int-only", action="store_true", help="skip the extra GET_INT_VECTOR measurement (profiler passes: one kernel per run)")
     ap.add_argument("--cpu-elems", type=int, default=6250000, help="elements in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -255,7 +256,7 @@ def main():
     # "also report the f_int-only call (it is the majority of calls under BFGS)" -- measured after, and outside,
     # the timed region of the headline metric, on the same context and state; the model must answer GET_INT_VECTOR
     fonly = None
-    if world == 1 and want_K and wl["model"] != capi.LINEAR_ELASTICITY:
+    if world == 1 and want_K and wl["model"] != capi.LINEAR_ELASTICITY and not args.no_f_int_only:
         for _ in range(3):
             asm.assemble(state, None, f, flags=flags)
         ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]

@@ -20,6 +20,9 @@
 #pragma once
 #include "fa_kernel_impl.h"
 
+#ifndef FA_TILE_UNROLL_IPMAJ
+#define FA_TILE_UNROLL_IPMAJ 1   /* 8 measured slower: cfg4 at 128^3 5.05 against 4.88 ms */
+#endif
 #ifndef FA_TILE_UNROLL_A
 #define FA_TILE_UNROLL_A 1
 #endif
@@ -111,8 +114,22 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   const bool fu = FU_CAP && P.tile_fu != 0;
   // ---- phase 1: Gauss points ----
   double err_acc = 0.0;
-  for (int t = tid; t < n_el * NIP; t += BLK) {
-    const int s = t / NIP, ip = t - s * NIP;
+  // Hex8: the lanes of a wave take ONE Gauss point of 64 different elements (point-major lane order) instead of the 8 points
+  // of 8 elements: the point index is wave-uniform, so the shape tables come through scalar loads instead of per-lane LDS
+  // reads, and the lanes of a wave add to the f rows of different nodes (on a structured mesh local node a of different
+  // elements is never the same node)
+  constexpr bool IPMAJ = (RANK == 3 && NPE == 8 && NIP == 8);
+  const int nel_pad = (n_el + 63) & ~63;
+  const const_dptr gN = (const_dptr)P.tab, gD = gN + NIP * NPE, gW = gN + NIP * NPE * (1 + RANK);
+  auto TN = [&](int idx) -> double { if constexpr (IPMAJ) return gN[idx]; else return tabN[idx]; };
+  auto TD = [&](int idx) -> double { if constexpr (IPMAJ) return gD[idx]; else return tabD[idx]; };
+  auto TW = [&](int idx) -> double { if constexpr (IPMAJ) return gW[idx]; else return tabW[idx]; };
+  for (int t = tid; t < (IPMAJ ? NIP * nel_pad : n_el * NIP); t += BLK) {
+    int s, ip;
+    if constexpr (IPMAJ) {
+      ip = __builtin_amdgcn_readfirstlane(t / nel_pad); s = t - ip * nel_pad;
+      if (s >= n_el) continue;
+    } else { s = t / NIP; ip = t - s * NIP; }
     const uint32_t ew = (uint32_t)P.telems[elem_off + s];
     const int64_t e = (int64_t)(ew & 0x7FFFFFFFu);
     const bool write = (ew >> 31) != 0;                // this tile stores the element's history / strain / errExt_
@@ -131,12 +148,12 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
       for (int k = 0; k < RANK; k++) { J[i][k] = 0.0; Fm[i][k] = 0.0; }
     }
     const bool lean = FU_CAP && fu;                      // only J is needed
-#pragma unroll FA_TILE_UNROLL_A
+#pragma unroll (IPMAJ ? FA_TILE_UNROLL_IPMAJ : FA_TILE_UNROLL_A)
     for (int a = 0; a < NPE; a++) {
       const double* nd = sNod + (int)lc[a] * NODW;
 #pragma unroll
       for (int k = 0; k < RANK; k++) {
-        const double dn = tabD[(ip * NPE + a) * RANK + k];
+        const double dn = TD((ip * NPE + a) * RANK + k);
 #pragma unroll
         for (int i = 0; i < RANK; i++) J[i][k] += nd[i] * dn;
         if (FUSED && !lean) {
@@ -146,7 +163,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
         }
       }
       if constexpr (FUSED && PF) {
-        const double Na = tabN[ip * NPE + a];
+        const double Na = TN(ip * NPE + a);
         pf += Na * nd[2 * RANK];
         if (SP::model(P) == 2 || SP::model(P) == 3) { pf0 += Na * sExt[2 * (int)lc[a]]; pfX += Na * sExt[2 * (int)lc[a] + 1]; }
         else if ((SP::model(P) == 5 || SP::model(P) == 6)) pfX += Na * sExt[2 * (int)lc[a] + 1];
@@ -174,7 +191,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
       inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
       inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
     }
-    const double w = tabW[ip] * det;
+    const double w = TW(ip) * det;
     if constexpr (FU_CAP) {
       if (fu) {                                        // f_int comes from the pair lanes (K u): the point only leaves J^-1 and w det J
         double* rec = sRec + s * SLOTW + ip * RW;
@@ -226,7 +243,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
       for (int i = 0; i < RANK; i++) {
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < RANK; k++) acc += tabD[(ip * NPE + a) * RANK + k] * inv[k][i];
+        for (int k = 0; k < RANK; k++) acc += TD((ip * NPE + a) * RANK + k) * inv[k][i];
         ga[i] = acc; ua[i] = nd[RANK + i];
       }
       if constexpr (WANT_K && TR::GREC) {
@@ -243,7 +260,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
         eps[5] += ga[0] * ua[2]; eps[5] += ga[2] * ua[0];
       }
       if constexpr (PF) {
-        const double Na = tabN[ip * NPE + a], ph = nd[2 * RANK];
+        const double Na = TN(ip * NPE + a), ph = nd[2 * RANK];
         pf += Na * ph;
 #pragma unroll
         for (int i = 0; i < RANK; i++) gphi[i] += ga[i] * ph;
@@ -328,7 +345,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
         if (li >= n_own) continue;
         double dn[RANK];
 #pragma unroll
-        for (int k = 0; k < RANK; k++) dn[k] = tabD[(ip * NPE + a) * RANK + k];
+        for (int k = 0; k < RANK; k++) dn[k] = TD((ip * NPE + a) * RANK + k);
 #pragma unroll
         for (int i = 0; i < RANK; i++) {
           double acc = 0.0;
@@ -337,7 +354,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
           atomicAdd(&sF[li * NDOF + i], acc);
         }
         if constexpr (PF) {
-          double acc = wcf * tabN[ip * NPE + a];
+          double acc = wcf * TN(ip * NPE + a);
 #pragma unroll
           for (int k = 0; k < RANK; k++) acc += dn[k] * G[k];
           atomicAdd(&sF[li * NDOF + RANK], acc);
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
       for (int i = 0; i < RANK; i++) {
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < RANK; k++) acc += tabD[(ip * NPE + a) * RANK + k] * inv[k][i];
+        for (int k = 0; k < RANK; k++) acc += TD((ip * NPE + a) * RANK + k) * inv[k][i];
         wga[i] = w * acc;
       }
       Bt_vec<RANK, S>(wga, m.sig, tt);
@@ -364,7 +381,7 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
         double gg = 0.0;
 #pragma unroll
         for (int i = 0; i < RANK; i++) gg += wga[i] * gphi[i];
-        atomicAdd(&sF[li * NDOF + RANK], (w * tabN[ip * NPE + a]) * m.cf + P.c2 * gg);
+        atomicAdd(&sF[li * NDOF + RANK], (w * TN(ip * NPE + a)) * m.cf + P.c2 * gg);
       }
     }
   }
