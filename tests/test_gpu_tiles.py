@@ -272,3 +272,65 @@ def test_value_array_that_is_only_8_byte_aligned(shape, mesh):
     torch.cuda.synchronize()
     assert (Ko - K).abs().max().item() <= 1e-13 * K.abs().max().item()
     assert big[0].item() == 5.0 and big[-1].item() == 5.0 and big[-2].item() == 5.0      # nothing written outside
+
+
+def test_full_size_invariants_cfg4():
+    """BASELINE config 4 at its full size (200^3 Hex8, u-phi, AT2, Amor; 3.47 G non-zeros): too large for the oracle, so
+    the tile kernel (box tiles, mirrored pair blocks, point-major Gauss-point lanes) and the Hex8 force-vector kernel
+    are checked through size-independent properties, as test_full_size_invariants_cfg3 does for the lane-pair kernel:
+    every entry of the pattern written, internal forces of every displacement component sum to zero and a rigid
+    translation is in the null space of the u-u block (partition of unity), exact zeros in the u-phi / phi-u blocks,
+    positive K4 row sums, K bitwise repeatable, FA_ACCUMULATE on a zeroed K equal to FA_OVERWRITE, and the
+    GET_INT_VECTOR pass (another kernel) returning the same f_int and history."""
+    import torch
+    n = 200
+    coords, conn = meshgen.grid_hex8(n, n, n)
+    kw = dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=False)
+    asm = capi.Assembler(capi.HEX8_G2, capi.PHASE_FRACTURE, capi.AMOR_PHASE, coords, conn, **kw)
+    assert asm.nel == n ** 3 and asm.nnz == 16 * (3 * n + 1) ** 3
+    dev = torch.device("cuda", 0)
+    st = torch.from_numpy(meshgen.smooth_state(coords, 4)).to(dev)
+    del coords, conn
+    K = torch.empty(asm.nnz, dtype=torch.float64, device=dev).fill_(float("nan"))
+    f = torch.empty(asm.ndof, dtype=torch.float64, device=dev).fill_(float("nan"))
+    asm.assemble(st, K, f, flags=capi.OVERWRITE)
+    torch.cuda.synchronize()
+    assert not torch.isnan(K).any() and not torch.isnan(f).any()
+    fmax = f.abs().max().item(); kmax = K.abs().max().item()
+    for c in range(3):
+        assert abs(f[c::4].sum().item()) < 1e-9 * fmax * np.sqrt(asm.ndof)
+    Kb = K.view(-1, 4)                                                           # blocked [neighbour][column type]
+    # first entry group of every row from the mesh itself (fetching the 3.47 G column indices would take minutes): a node
+    # of the structured grid has 2 or 3 neighbours per direction, each of its 4 rows holds that many groups of 4 entries
+    c1 = np.full(n + 1, 3, dtype=np.int64); c1[0] = c1[-1] = 2
+    deg = (c1[:, None, None] * c1[None, :, None] * c1[None, None, :]).ravel()    # any axis order: the product is symmetric
+    grp = torch.from_numpy(np.concatenate([[0], np.cumsum(np.repeat(deg, 4))])).to(dev)
+    assert int(grp[-1].item()) * 4 == asm.nnz
+    rowsum = torch.empty(asm.ndof, 4, dtype=torch.float64, device=dev)
+    for c in range(4):                                                           # one contiguous 1-D scan per column type
+        cs = torch.zeros(Kb.shape[0] + 1, dtype=torch.float64, device=dev)
+        torch.cumsum(Kb[:, c].contiguous(), 0, out=cs[1:])
+        rowsum[:, c] = cs[grp[1:]] - cs[grp[:-1]]
+        del cs
+    urows = torch.arange(asm.ndof, device=dev) % 4 < 3
+    assert rowsum[urows][:, :3].abs().max().item() < 1e-6 * kmax                 # translation null space (cumsum rounding)
+    assert rowsum[~urows][:, 3].min().item() > 0.0                               # K4 row sums
+    # exact zeros in the blocks the model does not write (differences of running sums cannot show that): entry by entry
+    g_is_u = torch.repeat_interleave(urows, grp[1:] - grp[:-1])                  # per entry group: does its row belong to u?
+    assert Kb[g_is_u][:, 3].abs().max().item() == 0.0                            # u-phi block
+    assert Kb[~g_is_u][:, :3].abs().max().item() == 0.0                          # phi-u block
+    del rowsum, Kb, grp, g_is_u
+    h1 = asm.get_history(1).copy()
+    f2 = torch.zeros_like(f)
+    asm.assemble(st, None, f2, flags=capi.OVERWRITE)                             # Hex8 force-vector kernel
+    torch.cuda.synchronize()
+    assert (f - f2).abs().max().item() < 1e-12 * fmax
+    assert np.abs(asm.get_history(1) - h1).max() <= 1e-13 * np.abs(h1).max()
+    K2 = torch.zeros_like(K); f3 = torch.zeros_like(f)
+    asm.assemble(st, K2, f3, flags=capi.ACCUMULATE)
+    torch.cuda.synchronize()
+    assert (K - K2).abs().max().item() < 1e-12 * kmax and (f - f3).abs().max().item() < 1e-12 * fmax
+    K2.zero_()
+    asm.assemble(st, K2, f3, flags=capi.OVERWRITE)
+    torch.cuda.synchronize()
+    assert torch.equal(K, K2)                                                    # one writer per entry, fixed summation order
