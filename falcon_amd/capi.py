@@ -198,6 +198,17 @@ class Assembler:
         _check(lib().fa_pattern_host(self.h, _np_ptr(rp), _np_ptr(ci)))
         return rp, ci
 
+    def row_ptr_device(self):
+        """The 64-bit row offsets as a torch tensor on the context's device, without a copy (fa_pattern_device): the view is
+        valid while the assembler lives; treat it as read-only."""
+        import torch
+        rp, ci = C.c_void_p(), C.c_void_p()
+        _check(lib().fa_pattern_device(self.h, C.byref(rp), C.byref(ci)))
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (self.ndof + 1,), "typestr": "<i8", "data": (rp.value, False), "version": 2}
+        return torch.as_tensor(_View(), device=torch.device("cuda", self.device))
+
     def pattern_device32(self):
         """(row_ptr, col_idx) device addresses of the pattern with 32-bit offsets (cuDSSSolver.cpp:655-663)."""
         rp, ci = C.c_void_p(), C.c_void_p()

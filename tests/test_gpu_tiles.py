@@ -334,3 +334,49 @@ def test_full_size_invariants_cfg4():
     asm.assemble(st, K2, f3, flags=capi.OVERWRITE)
     torch.cuda.synchronize()
     assert torch.equal(K, K2)                                                    # one writer per entry, fixed summation order
+
+
+def test_full_size_invariants_cfg5():
+    """BASELINE config 5 at its full size (125 x 125 x 128 Hex20, linear elasticity, Gauss 3x3x3; 4.3 G non-zeros): the
+    tile kernel's grouped pair lanes and its K-u force path through size-independent properties -- every entry written,
+    internal forces in equilibrium, rigid translations in the null space of K (row sums per column type), K bitwise
+    repeatable, f_int from the pair blocks (K u) equal to f_int from the Gauss points (the pass with a strain cache),
+    FA_ACCUMULATE on a zeroed K equal to FA_OVERWRITE."""
+    import torch
+    coords, conn = meshgen.grid_hex20(125, 125, 128)
+    asm = capi.Assembler(capi.HEX20_G3, capi.LINEAR_ELASTICITY, capi.HOOKE, coords, conn, young=210e3, poisson=0.3)
+    assert asm.nel == 125 * 125 * 128
+    dev = torch.device("cuda", 0)
+    st = torch.from_numpy(meshgen.smooth_state(coords, 3)).to(dev)
+    del coords, conn
+    K = torch.empty(asm.nnz, dtype=torch.float64, device=dev).fill_(float("nan"))
+    f = torch.empty(asm.ndof, dtype=torch.float64, device=dev).fill_(float("nan"))
+    asm.assemble(st, K, f, flags=capi.OVERWRITE)                                 # f_int = K u from the pair lanes
+    torch.cuda.synchronize()
+    assert not torch.isnan(K).any() and not torch.isnan(f).any()
+    fmax = f.abs().max().item(); kmax = K.abs().max().item()
+    for c in range(3):
+        assert abs(f[c::3].sum().item()) < 1e-9 * fmax * np.sqrt(asm.ndof)
+    Kb = K.view(-1, 3)                                                           # blocked [neighbour][column type]
+    grp = asm.row_ptr_device() // 3
+    assert int(grp[-1].item()) * 3 == asm.nnz
+    worst = 0.0
+    for c in range(3):
+        cs = torch.zeros(Kb.shape[0] + 1, dtype=torch.float64, device=dev)
+        torch.cumsum(Kb[:, c].contiguous(), 0, out=cs[1:])
+        worst = max(worst, (cs[grp[1:]] - cs[grp[:-1]]).abs().max().item())
+        del cs
+    assert worst < 1e-6 * kmax                                                   # translation null space (running-sum rounding)
+    del Kb, grp
+    f2 = torch.zeros_like(f)
+    asm.assemble(st, None, f2, flags=capi.OVERWRITE)                             # f_int = sum w B^t sigma at the Gauss points
+    torch.cuda.synchronize()
+    assert (f - f2).abs().max().item() < 1e-10 * fmax
+    K2 = torch.zeros_like(K); f3 = torch.zeros_like(f)
+    asm.assemble(st, K2, f3, flags=capi.ACCUMULATE)
+    torch.cuda.synchronize()
+    assert (K - K2).abs().max().item() < 1e-12 * kmax and (f - f3).abs().max().item() < 1e-10 * fmax
+    K2.zero_()
+    asm.assemble(st, K2, f3, flags=capi.OVERWRITE)
+    torch.cuda.synchronize()
+    assert torch.equal(K, K2)
