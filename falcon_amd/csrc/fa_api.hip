@@ -830,11 +830,12 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   // ---- node tiles (tile kernel: GET_MATRIX0 passes of the 3-D shapes) ----
   fa::TileSet ts;
   {
-    // default: the higher-order shapes (they have no row kernel) and Hex8 with an isotropic-form tangent (the
-    // general-tangent records are too large for a good Hex8 tile: the row kernel stays faster there).
+    // default: the higher-order shapes (they have no row kernel) and Hex8.
     // FA_TILES=0 / 1 turns the tile kernel off / on for every shape (experiments).
     const bool env = dbg.tiles >= 0;
-    const bool wanted = env ? (dbg.tiles != 0) : (c->coop || (p->shape == FA_HEX8_G2 && c->fam != fa::FAM_PF_MIEHE));
+    // (Hex8 with a general tangent -- MiehePhase, the micromorphic models -- as well since the 3 x 3 x 3 box tiles: its 32-double
+    // records take the 1024-thread geometry, 6.55 ms against 8.8 ms for the row kernel on cfg4 / MiehePhase at 96^3)
+    const bool wanted = env ? (dbg.tiles != 0) : (c->coop || p->shape == FA_HEX8_G2);
 
     if (P.canon && wanted && nel > 0) {
       const bool keepK = P.keep2 || P.keep3;
