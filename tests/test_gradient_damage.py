@@ -310,3 +310,43 @@ def test_gpu_gradient_damage_refusals():
     with pytest.raises(capi.FaError):                                         # vonMises (2) and anything else
         capi.Assembler(capi.QUAD4_G2, capi.GRADIENT_DAMAGE, capi.DAMAGE, coords, conn, young=E, poisson=NU,
                        softening=capi.SOFT_PERFECT, kappa_i=1e-3, eqv_strain=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [po.QUAD4_G2, po.TRI3_G1, po.HEX8_G2])
+def test_gpu_gradient_damage_deterministic_and_generic_paths(shape):
+    """FA_DETERMINISTIC (ordered row kernel / force-vector kernel) and FA_FORCE_GENERIC (per-entry column search) run the
+    GradientDamage instantiations of those kernels: bitwise repeatable, and within 1e-12 of the oracle."""
+    import torch
+    from falcon_amd import capi
+    from tests.conftest import rel_rowmax_err
+    rank, npe, nip, _ = po.shape_info(shape)
+    coords, conn = GPU_MESH[shape]()
+    coords = meshgen.distort(coords, conn, 0.12, 2)
+    soft, eqv = po.SOFT_EXPONENTIAL1, po.EQV_MAZARS
+    cfg = gd_config(shape, soft, po.PLANE_STRAIN, eqv=eqv)
+    st = gd_state(coords, rank)
+    H0 = gd_history(conn.shape[0] * nip)
+    asm = capi.Assembler(shape, capi.GRADIENT_DAMAGE, capi.DAMAGE, coords, conn, young=E, poisson=NU, softening=soft,
+                         length_scale=0.02, eqv_strain=eqv, **LAWS[soft])
+    rp, ci = asm.pattern()
+    ref = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=H0)
+    dev = torch.device("cuda", 0)
+    dst = torch.from_numpy(st).to(dev)
+    asm.set_history(0, H0)
+    outs = []
+    for flags in (capi.OVERWRITE | capi.DETERMINISTIC, capi.OVERWRITE | capi.DETERMINISTIC, capi.OVERWRITE | capi.FORCE_GENERIC):
+        K = torch.full((asm.nnz,), 5.0, dtype=torch.float64, device=dev); f = torch.full((asm.ndof,), 5.0, dtype=torch.float64, device=dev)
+        asm.assemble(dst, K, f, flags=flags)
+        torch.cuda.synchronize()
+        assert rel_rowmax_err(rp, K.cpu().numpy(), ref["K"]) < 1e-12
+        assert np.abs(f.cpu().numpy() - ref["f"]).max() < 1e-12 * np.abs(ref["f"]).max()
+        assert np.array_equal(asm.get_history(1) < 0, ref["hist_new"] < 0)
+        outs.append((K, f))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    f2 = torch.zeros_like(outs[0][1])
+    asm.assemble(dst, None, f2, flags=capi.OVERWRITE | capi.DETERMINISTIC)
+    f3 = torch.zeros_like(f2)
+    asm.assemble(dst, None, f3, flags=capi.OVERWRITE | capi.DETERMINISTIC)
+    torch.cuda.synchronize()
+    assert torch.equal(f2, f3) and (f2 - outs[0][1]).abs().max().item() < 1e-12 * np.abs(ref["f"]).max()
