@@ -16,7 +16,8 @@ TRI3_G1, TRI3_G3, QUAD4_G2, QUAD8_G3, QUAD8_G2, TRI6_G3, HEX8_G2, HEX20_G3, HEX2
 (LINEAR_ELASTICITY, PHASE_FRACTURE, PHASE_FRACTURE_EXT, PHASE_FRACTURE_EXTIT, MICRO_PHASE_FRACTURE,
  MICRO_PHASE_FRACTURE_EXT, MICRO_PHASE_FRACTURE_EXTIT, GRADIENT_DAMAGE) = range(8)
 HOOKE, AMOR_PHASE, BOURDIN_PHASE, MIEHE_PHASE, DAMAGE = range(5)
-SOFT_PERFECT, SOFT_LINEAR1, SOFT_LINEAR2, SOFT_EXPONENTIAL1, SOFT_EXPONENTIAL2 = range(5)
+(SOFT_PERFECT, SOFT_LINEAR1, SOFT_LINEAR2, SOFT_EXPONENTIAL1, SOFT_EXPONENTIAL2, SOFT_POWER, SOFT_HYPERBOLIC,
+ SOFT_EXPONENTIAL2REG, SOFT_EXPOENERGY, SOFT_POLYNOMIAL, SOFT_MULTILINEAR) = range(11)
 EQV_ENERGY, EQV_MAZARS = 0, 1
 PLANE_STRAIN, PLANE_STRESS = 0, 1
 AT1, AT2, CZM_LINEAR, CZM_EXPONENTIAL, CZM_CORNELISSEN, CZM_HYPERBOLIC = range(6)
@@ -43,7 +44,8 @@ class Problem(C.Structure):
                 ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("node_dofs", C.c_void_p),
                 ("ndof", C.c_int64), ("pattern_kind", C.c_int32), ("device", C.c_int32),
                 ("softening", C.c_int32), ("kappa_i", C.c_double), ("kappa_c", C.c_double), ("soft_alpha", C.c_double),
-                ("soft_beta", C.c_double), ("length_scale", C.c_double), ("eqv_strain", C.c_int32)]
+                ("soft_beta", C.c_double), ("length_scale", C.c_double), ("eqv_strain", C.c_int32),
+                ("soft_b", C.c_double), ("soft_s", C.c_double), ("kappa_p", C.c_double)]
 
 
 class AssembleArgs(C.Structure):
@@ -148,7 +150,8 @@ class Assembler:
     def __init__(self, shape, model, material, coords, conn, *, state=PLANE_STRAIN, young=210e3, poisson=0.3,
                  frac_type=AT2, gc=2.7, l0=0.015, sigma_t=0.0, beta=6500.0, keep_off_diags=False,
                  row_ptr=None, col_idx=None, node_dofs=None, ndof=0, pattern_kind=PATTERN_FULL, device=0,
-                 softening=0, kappa_i=0.0, kappa_c=0.0, soft_alpha=0.0, soft_beta=0.0, length_scale=0.0, eqv_strain=0):
+                 softening=0, kappa_i=0.0, kappa_c=0.0, soft_alpha=0.0, soft_beta=0.0, length_scale=0.0, eqv_strain=0,
+                 soft_b=0.0, soft_s=0.0, kappa_p=0.0):
         coords = np.ascontiguousarray(coords, dtype=np.float64)
         conn = np.ascontiguousarray(conn, dtype=np.int32)
         rank, npe, nip = SHAPE_INFO[shape]
@@ -166,7 +169,8 @@ class Assembler:
         p = Problem(shape, model, material, state, young, poisson, frac_type, gc, l0, sigma_t, beta,
                     int(bool(keep_off_diags)), coords.shape[0], _np_ptr(coords), conn.shape[0], _np_ptr(conn),
                     _np_ptr(row_ptr), _np_ptr(col_idx), _np_ptr(node_dofs), ndof, pattern_kind, device,
-                    softening, kappa_i, kappa_c, soft_alpha, soft_beta, length_scale, eqv_strain)
+                    softening, kappa_i, kappa_c, soft_alpha, soft_beta, length_scale, eqv_strain,
+                    soft_b, soft_s, kappa_p)
         self.h = C.c_void_p()
         _check(lib().fa_create(C.byref(p), C.byref(self.h)))
         L = lib()

@@ -423,13 +423,18 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   // GradientDamageModel.cpp:205-206 dynamicCast<DamageMaterial>
   if (gd != (p->material == FA_DAMAGE)) return fail(FA_ERR_ARG, "GradientDamage needs material Damage, and only GradientDamage takes it");
   if (gd) {
-    if (p->softening < FA_SOFT_PERFECT || p->softening > FA_SOFT_EXPONENTIAL2)
-      return fail(FA_ERR_ARG, "unexpected definition of softening law!!! Supported here: perfect, linear1, linear2, exponential1, exponential2");
+    if (p->softening < FA_SOFT_PERFECT || p->softening > FA_SOFT_MULTILINEAR)
+      return fail(FA_ERR_ARG, "unexpected definition of softening law!!! (0 ... 10, the order of DamageMaterial's softeningLawDefs)");
     if (!(p->kappa_i > 0.0)) return fail(FA_ERR_ARG, "Damage: kappaI (or ft / young) must be positive");
     if (p->eqv_strain != FA_EQV_ENERGY && p->eqv_strain != FA_EQV_MAZARS)
       return fail(FA_ERR_ARG, "unexpected definition of equivalent strain!!! Available here: Energy, Mazars");
-    if ((p->softening == FA_SOFT_LINEAR1 || p->softening == FA_SOFT_LINEAR2 || p->softening == FA_SOFT_EXPONENTIAL2) && !(p->kappa_c > p->kappa_i))
+    const int sl = p->softening;
+    if ((sl == FA_SOFT_LINEAR1 || sl == FA_SOFT_LINEAR2 || sl == FA_SOFT_EXPONENTIAL2 || sl == FA_SOFT_POWER || sl == FA_SOFT_POLYNOMIAL) &&
+        !(p->kappa_c > p->kappa_i))
       return fail(FA_ERR_ARG, "Damage: kappaC must exceed kappaI");
+    if (sl == FA_SOFT_HYPERBOLIC && !(p->soft_b >= 0.0)) return fail(FA_ERR_ARG, "Damage: b must not be negative");
+    if (sl == FA_SOFT_EXPOENERGY && !(p->kappa_c > 0.0 && p->soft_s >= 0.0)) return fail(FA_ERR_ARG, "Damage: expoEnergy needs kappaC > 0 and s >= 0");
+    if (sl == FA_SOFT_MULTILINEAR && !(p->kappa_p >= 0.0 && p->kappa_c > p->kappa_p)) return fail(FA_ERR_ARG, "Damage: multilinear needs kappaC > kappaP >= 0");
   }
   c->fam = !pf ? fa::FAM_LE : (p->material == FA_MIEHE_PHASE ? fa::FAM_PF_MIEHE : fa::FAM_PF_ISO);
   if (p->model >= FA_MICRO_PHASE_FRACTURE && p->model <= FA_MICRO_PHASE_FRACTURE_EXTIT) {
@@ -491,6 +496,10 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   if (gd) {                                            // all four blocks (GradientDamageModel.cpp:577-583); c2 = c (:438, :563)
     P.keep2 = 1; P.keep3 = 1; P.c2 = p->length_scale; P.psi0 = 0.0; P.gcl = 0.0;
     P.soft = p->softening; P.kI = p->kappa_i; P.kC = p->kappa_c; P.sA = p->soft_alpha; P.sB = p->soft_beta;
+    // the one-parameter laws borrow sA: hyperbolic b, expoEnergy s, multilinear kappaP
+    if (p->softening == FA_SOFT_HYPERBOLIC) P.sA = p->soft_b;
+    if (p->softening == FA_SOFT_EXPOENERGY) P.sA = p->soft_s;
+    if (p->softening == FA_SOFT_MULTILINEAR) P.sA = p->kappa_p;
     P.eqv = p->eqv_strain; P.k2sig = (p->eqv_strain != FA_EQV_ENERGY) ? 1 : 0;
     P.pstress = (sh.rank == 2 && p->state == FA_PLANE_STRESS) ? 1 : 0; P.poiD = p->poisson / (p->poisson - 1.0);
   }

@@ -640,11 +640,42 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
             if (K >= Ki) omega = 1.0 - (Ki / K) * (1.0 - P.sA + P.sA * ex);
             const double a = Ki / (K * K), b = a * K, c = P.sA * ex;
             domega = a * (1.0 - P.sA + c) + P.sB * b * c;
-          } else {
+          } else if (P.soft == 4) {
             const double ex = exp((Ki - K) / (Kc - Ki));
             if (K >= Ki) omega = 1.0 - (Ki / K) * ex;
             const double d = Ki / (K * K);
             domega = d * ex + d * K * ex / (Kc - Ki);
+          } else if (P.soft == 5) {                       // power (:1389-1413, :1446-1472), Kcc = Kc
+            const double a = Ki / K, b = 1.0 / (Kc - Ki), c = (Kc - K) * b;
+            if (K >= Ki) {
+              const double omegac = 1.0 - pow(Ki / Kc, P.sB) * pow((Kc - Kc) / (Kc - Ki), P.sA);
+              omega = (K > Kc) ? omegac : 1.0 - pow(a, P.sB) * pow((Kc - K) / (Kc - Ki), P.sA);
+            }
+            domega = (K > Kc) ? 0.0 : pow(a, P.sB - 1.0) * pow(c, P.sA - 1.0) * ((a / K) * P.sB * c + a * P.sA * b);
+          } else if (P.soft == 6) {                       // hyperbolic (:1350-1380), sA = b; isTiny as in the checker
+            const double q = 1.0 + P.sA * (K - Ki);
+            if (K >= Ki) { omega = 1.0 - 1.0 / q; if (fabs(1.0 - omega) < 2.2250738585072014e-308) omega = 0.999; }
+            domega = P.sA / q / q;
+          } else if (P.soft == 7) {                       // exponential2Reg: not in the overloads GradientDamage reaches
+          } else if (P.soft == 8) {                       // expoEnergy (:1495-1523), sA = s
+            if (K >= Ki) {
+              const double t = (K - Ki) / Kc, tem1 = pow(t, P.sA), tem2 = pow(t, P.sA - 1.0);
+              omega = 1.0 - exp(-tem1);
+              domega = exp(-tem1) * tem2 * P.sA / Kc;
+            }
+          } else if (P.soft == 9) {                       // polynomial (:1530-1574); d from the un-normalised a, verbatim
+            if (K >= Ki) {
+              const double an = (K - Ki) / (Kc - Ki);
+              omega = 1.0 - (Ki / K) * (1.0 + (an * an) * (2.0 * an - 3.0));
+              const double a = Ki - K, b = Kc - Ki, c = a / b, d = 1.0 + (a * a) * (2.0 * a - 3.0);
+              domega = -Ki / (K * K) * (2.0 * K * (c / b * (2.0 * c - 3.0) + (c * c) / b) - d);
+            }
+          } else {                                        // multilinear (:1581-1633), sA = kappaP
+            const double Kp = P.sA;
+            if (K >= Ki) {
+              if (K > Kp) { omega = 1.0 - Ki / K; domega = Ki / (K * K); }
+              else { omega = (K < Kp) ? 0.0 : (K > Kc ? 0.999 : (K - Kp) / (Kc - Kp)); domega = (K < Kc) ? 1.0 / (Kc - Kp) : 0.0; }
+            }
           }
         }
         const double s1 = 1.0 - omega;

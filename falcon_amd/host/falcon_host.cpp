@@ -456,17 +456,25 @@ class SolidAssemblyModel : public Model {
     if (kappaI_ < 0) throw Error(props.context, "property `kappaI' out of range");
     props.find(lengthScale_, "lengthScale");
     std::string soft; props.get(soft, "softening");
-    static const char* LAWS[11] = { "perfect", "linear1", "linear2", "exponential1", "exponential2", "exponential2Reg", "power",
-                                    "hyperbolic", "expoEnergy", "polynomial", "multilinear" };
+    static const char* LAWS[11] = { "perfect", "linear1", "linear2", "exponential1", "exponential2", "power", "hyperbolic",
+                                    "exponential2Reg", "expoEnergy", "polynomial", "multilinear" };   // softeningLawDefs, :134-144
     int law = -1;
     for (int k = 0; k < 11; k++) if (soft == LAWS[k]) law = k;
     if (law < 0)
       throw Error("DamageMaterial::configure", "unexpected definition of softening law!!!\nSupported softening laws include: \n"
                   "perfect, linear1, linear2, exponential1, exponential2, power, hyperbolic, polynomial, multilinear");
-    if (law > 4) throw Error(props.context, "softening law `" + soft + "' is not available on the GPU assembly path (perfect, linear1, linear2, exponential1, exponential2 are)");
     softening_ = law;
-    if (law == FA_SOFT_EXPONENTIAL1) { props.get(softAlpha_, "alpha"); props.get(softBeta_, "beta"); }
-    if (law == FA_SOFT_EXPONENTIAL2 || law == FA_SOFT_LINEAR1 || law == FA_SOFT_LINEAR2) props.get(kappaC_, "kappaC");
+    auto need = [&](double& v, const char* name, double lo) {           // props.get (v, name, lo, maxOf (v))
+      props.get(v, name);
+      if (v < lo) throw Error(props.context, std::string("property `") + name + "' out of range");
+    };
+    if (law == FA_SOFT_EXPONENTIAL1) { need(softAlpha_, "alpha", 0.0); need(softBeta_, "beta", 0.0); }                 // :210-216
+    if (law == FA_SOFT_EXPONENTIAL2 || law == FA_SOFT_LINEAR1 || law == FA_SOFT_LINEAR2 || law == FA_SOFT_POLYNOMIAL)
+      need(kappaC_, "kappaC", 0.0);                                                                                    // :217-222, :241-252, :261-266
+    if (law == FA_SOFT_POWER) { need(kappaC_, "kappaC", 0.0); need(softAlpha_, "alpha", 0.0); need(softBeta_, "beta", 0.0); }   // :227-234
+    if (law == FA_SOFT_HYPERBOLIC) need(softB_, "b", 0.0);                                                             // :235-240
+    if (law == FA_SOFT_EXPOENERGY) { need(kappaI_, "kappaI", 0.0); need(kappaC_, "kappaC", 0.0); need(softS_, "s", 0.0); }      // :253-260
+    if (law == FA_SOFT_MULTILINEAR) { need(kappaP_, "kappaP", 0.0); need(kappaC_, "kappaC", kappaP_); }                // :267-273
     std::string eq; props.get(eq, "eqvStrain");
     if (eq == "Mazars") eqvStrain_ = FA_EQV_MAZARS;
     else if (eq == "Energy") eqvStrain_ = FA_EQV_ENERGY;
@@ -550,6 +558,7 @@ class SolidAssemblyModel : public Model {
     p.young = young_; p.poisson = poisson_; p.frac_type = fracType_ < 0 ? FA_AT2 : fracType_;
     p.gc = gc_; p.l0 = l0_; p.sigma_t = sigmaT_; p.beta = beta_; p.keep_off_diags = keepOffDiags_ ? 1 : 0;
     p.softening = softening_; p.kappa_i = kappaI_; p.kappa_c = kappaC_; p.soft_alpha = softAlpha_; p.soft_beta = softBeta_;
+    p.soft_b = softB_; p.soft_s = softS_; p.kappa_p = kappaP_;
     p.length_scale = lengthScale_; p.eqv_strain = eqvStrain_;
     p.nnode = (int64_t)nodes_.size(); p.coords = xc.data();
     p.nel = (int64_t)ielems_.size(); p.conn = conn.data();
@@ -633,7 +642,7 @@ class SolidAssemblyModel : public Model {
   double gc_ = 2.7, l0_ = 0.015, sigmaT_ = 0.0, beta_ = 6500.0;   // PhaseFractureModel.cpp:253-263, Ext :247
   double dt_ = 0.0, dt0_ = 0.0, errExt_ = 0.0;
   int softening_ = 0, eqvStrain_ = 0;                         // DamageMaterial (GradientDamage)
-  double kappaI_ = 0.0, kappaC_ = 0.0, softAlpha_ = 0.0, softBeta_ = 0.0, lengthScale_ = 0.0;
+  double kappaI_ = 0.0, kappaC_ = 0.0, softAlpha_ = 0.0, softBeta_ = 0.0, lengthScale_ = 0.0, softB_ = 0.0, softS_ = 0.0, kappaP_ = 0.0;
   bool extFail_ = false; int oIter_ = 0, oMaxIter_ = 5000; double oTol_ = 1.e-3;
   std::vector<double> stateExt_;
   fa_ctx* ctx_ = nullptr;

@@ -55,9 +55,14 @@ enum { FA_HOOKE = 0, FA_AMOR_PHASE = 1, FA_BOURDIN_PHASE = 2, FA_MIEHE_PHASE = 3
 /* eqvStrain of the Damage material */
 enum { FA_EQV_ENERGY = 0, FA_EQV_MAZARS = 1 };
 
-/* softening (DamageMaterial.cpp:182-268; the laws are the free functions of :1044-1260) */
-enum { FA_SOFT_PERFECT = 0, FA_SOFT_LINEAR1 = 1, FA_SOFT_LINEAR2 = 2, FA_SOFT_EXPONENTIAL1 = 3 /* alpha, beta */,
-       FA_SOFT_EXPONENTIAL2 = 4 /* kappaC */ };
+/* softening (DamageMaterial.cpp:182-273; the laws are the free functions of :1044-1633), numbered like
+ * softeningLawDefs (:134-144).  "exponential2Reg" is accepted by the reference but absent from the damageEvolution_ /
+ * getdOmegadKappa overloads GradientDamage reaches (:802-851, :712-761): omega = 0 throughout, as there. */
+enum { FA_SOFT_PERFECT = 0, FA_SOFT_LINEAR1 = 1 /* kappaC */, FA_SOFT_LINEAR2 = 2 /* kappaC */,
+       FA_SOFT_EXPONENTIAL1 = 3 /* alpha, beta */, FA_SOFT_EXPONENTIAL2 = 4 /* kappaC */,
+       FA_SOFT_POWER = 5 /* kappaC, alpha, beta */, FA_SOFT_HYPERBOLIC = 6 /* b */, FA_SOFT_EXPONENTIAL2REG = 7,
+       FA_SOFT_EXPOENERGY = 8 /* kappaC, s */, FA_SOFT_POLYNOMIAL = 9 /* kappaC */,
+       FA_SOFT_MULTILINEAR = 10 /* kappaP, kappaC */ };
 
 /* material.state, src/materials/HookeMaterial.cpp:92-103 */
 enum { FA_PLANE_STRAIN = 0, FA_PLANE_STRESS = 1 };
@@ -112,6 +117,7 @@ typedef struct {
   int32_t softening;
   double  kappa_i, kappa_c, soft_alpha, soft_beta, length_scale;
   int32_t eqv_strain;                          /* FA_EQV_ENERGY / FA_EQV_MAZARS (eqvStrain, DamageMaterial.cpp:275-308) */
+  double  soft_b, soft_s, kappa_p;             /* hyperbolic "b" (:237), expoEnergy "s" (:257), multilinear "kappaP" (:271) */
 } fa_problem;
 
 typedef struct {

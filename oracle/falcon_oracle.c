@@ -834,18 +834,37 @@ static int add_block(const int64_t* row_ptr, const int32_t* col_idx, double* val
 /* The hot loop                                                              */
 /* ------------------------------------------------------------------------- */
 /* ---- DamageMaterial, restated for eqvStrain = Energy (DamageMaterial.cpp:645-650, :700-705) ---- */
-static double damage_evolution(const fo_config* c, double K) {          /* damageEvolution_, :802-855, laws :1044-1290 */
+static double damage_evolution(const fo_config* c, double K) {          /* damageEvolution_, :802-855, laws :1044-1633 */
   const double Ki = c->kappa_i, Kc = c->kappa_c;
-  if (K < Ki) return 0.0;
+  if (K < Ki) return 0.0;                                               /* first statement of every law */
   switch (c->softening) {
     case FO_SOFT_PERFECT: return 1.0 - Ki / K;
     case FO_SOFT_LINEAR1: { double omega = K > Kc ? 1.0 : Kc * (K - Ki) / (K * (Kc - Ki)); if (omega == 1.0) omega = 0.999; return omega; }
     case FO_SOFT_LINEAR2: return K > Kc ? 0.999 : (K - Ki) / (Kc - Ki);
     case FO_SOFT_EXPONENTIAL1: return 1.0 - (Ki / K) * (1.0 - c->soft_alpha + c->soft_alpha * exp(-c->soft_beta * (K - Ki)));
-    default: return 1.0 - (Ki / K) * exp((Ki - K) / (Kc - Ki));
+    case FO_SOFT_EXPONENTIAL2: return 1.0 - (Ki / K) * exp((Ki - K) / (Kc - Ki));
+    case FO_SOFT_POWER: {                                               /* powerSoftening, :1389-1413 (Kcc = Kc) */
+      const double Kcc = Kc;
+      const double omegac = 1.0 - pow(Ki / Kcc, c->soft_beta) * pow((Kc - Kcc) / (Kc - Ki), c->soft_alpha);
+      return (K > Kcc) ? omegac : 1.0 - pow(Ki / K, c->soft_beta) * pow((Kc - K) / (Kc - Ki), c->soft_alpha);
+    }
+    case FO_SOFT_HYPERBOLIC: {                                          /* hyperbolicSoftening, :1350-1364 */
+      const double omega = 1.0 - 1.0 / (1.0 + c->soft_b * (K - Ki));
+      /* jem::isTiny(1 - omega): Jem's threshold is not visible here; DBL_MIN stands in (only b (K - Ki) > 4e307 gets there) */
+      return (fabs(1.0 - omega) < 2.2250738585072014e-308) ? 0.999 : omega;
+    }
+    case FO_SOFT_EXPONENTIAL2REG: return 0.0;       /* not in the one-argument damageEvolution_ (:802-851): omega stays 0 */
+    case FO_SOFT_EXPOENERGY: { const double tem = pow((K - Ki) / Kc, c->soft_s); return 1.0 - exp(-tem); }   /* :1495-1505 */
+    case FO_SOFT_POLYNOMIAL: { const double a = (K - Ki) / (Kc - Ki); return 1.0 - (Ki / K) * (1.0 + (pow(a, 2.0) * (2.0 * a - 3.0))); } /* :1530-1546 */
+    default: {                                                          /* multilinearSoftening, :1581-1603 */
+      const double Kp = c->kappa_p;
+      if (K > Kp) return 1.0 - Ki / K;
+      if (K < Kp) return 0.0;                                           /* linear2Softening (Kp, Kc, K) */
+      return K > Kc ? 0.999 : (K - Kp) / (Kc - Kp);
+    }
   }
 }
-static double damage_derivative(const fo_config* c, double K) {         /* getdOmegadKappa, :712-765 */
+static double damage_derivative(const fo_config* c, double K) {         /* getdOmegadKappa, :712-761 */
   const double Ki = c->kappa_i, Kc = c->kappa_c;
   switch (c->softening) {
     case FO_SOFT_PERFECT: return (K < Ki) ? 0.0 : Ki / (K * K);
@@ -855,7 +874,31 @@ static double damage_derivative(const fo_config* c, double K) {         /* getdO
       const double h = K - Ki, a = Ki / (K * K), b = a * K, cc = c->soft_alpha * exp(-c->soft_beta * h);
       return a * (1.0 - c->soft_alpha + cc) + c->soft_beta * b * cc;
     }
-    default: { const double a = Ki - K, b = Kc - Ki, cc = exp(a / b), d = Ki / (K * K); return d * cc + d * K * cc / b; }
+    case FO_SOFT_EXPONENTIAL2: { const double a = Ki - K, b = Kc - Ki, cc = exp(a / b), d = Ki / (K * K); return d * cc + d * K * cc / b; }
+    case FO_SOFT_POWER: {                                               /* getDerivPowerSoftening, :1446-1472 */
+      if (K > Kc) return 0.0;
+      const double a = Ki / K, b = 1.0 / (Kc - Ki), cc = (Kc - K) * b;
+      const double d = pow(a, c->soft_beta - 1.0), e = pow(cc, c->soft_alpha - 1.0);
+      return d * e * ((a / K) * c->soft_beta * cc + a * c->soft_alpha * b);
+    }
+    case FO_SOFT_HYPERBOLIC: return c->soft_b / (1.0 + c->soft_b * (K - Ki)) / (1.0 + c->soft_b * (K - Ki));   /* :1370-1380 */
+    case FO_SOFT_EXPONENTIAL2REG: return 0.0;       /* not in the one-argument getdOmegadKappa (:712-761) */
+    case FO_SOFT_EXPOENERGY: {                                          /* :1512-1523 */
+      if (K < Ki) return 0.0;
+      const double tem1 = pow((K - Ki) / Kc, c->soft_s), tem2 = pow((K - Ki) / Kc, c->soft_s - 1);
+      return exp(-tem1) * tem2 * c->soft_s / Kc;
+    }
+    case FO_SOFT_POLYNOMIAL: {                      /* :1553-1574, verbatim: d is built from the un-normalised a = Ki - K */
+      if (K < Ki) return 0.0;
+      const double a = (Ki - K), b = (Kc - Ki), cc = a / b, d = 1.0 + (pow(a, 2.0) * (2.0 * a - 3.0));
+      return -Ki / (K * K) * (2.0 * K * (cc / b * (2.0 * cc - 3.0) + pow(cc, 2.0) / b) - d);
+    }
+    default: {                                                          /* getDerivMultilinearSoftening, :1610-1633 */
+      const double Kp = c->kappa_p;
+      if (K < Ki) return 0.0;
+      if (K > Kp) return Ki / (K * K);
+      return (K < Kc) ? 1.0 / (Kc - Kp) : 0.0;                          /* getDerivLinear2Softening (Kp, Kc, K) */
+    }
   }
 }
 

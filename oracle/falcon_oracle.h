@@ -53,8 +53,10 @@ enum {
 /* material ids: newMaterial, src/materials/Material.cpp:233-244 */
 enum { FO_HOOKE = 0, FO_AMOR = 1, FO_BOURDIN = 2, FO_MIEHE = 3, FO_DAMAGE = 4 };
 
-/* DamageMaterial softening laws restated (DamageMaterial.cpp:1044-1290) */
-enum { FO_SOFT_PERFECT = 0, FO_SOFT_LINEAR1 = 1, FO_SOFT_LINEAR2 = 2, FO_SOFT_EXPONENTIAL1 = 3, FO_SOFT_EXPONENTIAL2 = 4 };
+/* DamageMaterial softening laws restated (DamageMaterial.cpp:1044-1633) */
+enum { FO_SOFT_PERFECT = 0, FO_SOFT_LINEAR1 = 1, FO_SOFT_LINEAR2 = 2, FO_SOFT_EXPONENTIAL1 = 3, FO_SOFT_EXPONENTIAL2 = 4,
+       FO_SOFT_POWER = 5, FO_SOFT_HYPERBOLIC = 6, FO_SOFT_EXPONENTIAL2REG = 7, FO_SOFT_EXPOENERGY = 8, FO_SOFT_POLYNOMIAL = 9,
+       FO_SOFT_MULTILINEAR = 10 };   /* the order of softeningLawDefs, DamageMaterial.cpp:134-144 */
 
 /* DamageMaterial equivalent strains restated: "Energy" (:644-649, :698-703) and "Mazars" (:618-642, :886-1032); the
  * vonMises one returns a 6-vector for 2-D strains (:677-683) whose use in GradientDamageModel.cpp:548 is out of bounds */
@@ -84,6 +86,7 @@ typedef struct {
   int    softening;
   double kappa_i, kappa_c, soft_alpha, soft_beta, length_scale;
   int    eqv_strain;     /* FO_EQV_ENERGY / FO_EQV_MAZARS (DamageMaterial.cpp:275-308) */
+  double soft_b, soft_s, kappa_p;   /* hyperbolic b (:237), expoEnergy s (:257), multilinear kappaP (:271) */
 } fo_config;
 
 typedef struct {

@@ -21,7 +21,8 @@ TRI3_G1, TRI3_G3, QUAD4_G2, QUAD8_G3, QUAD8_G2, TRI6_G3, HEX8_G2, HEX20_G3, HEX2
 HISTORY_MODELS = (PHASE_FRACTURE, MICRO_PHASE_FRACTURE, MICRO_EXT, MICRO_EXTIT, GRADIENT_DAMAGE)
 # materials
 HOOKE, AMOR, BOURDIN, MIEHE, DAMAGE = range(5)
-SOFT_PERFECT, SOFT_LINEAR1, SOFT_LINEAR2, SOFT_EXPONENTIAL1, SOFT_EXPONENTIAL2 = range(5)
+(SOFT_PERFECT, SOFT_LINEAR1, SOFT_LINEAR2, SOFT_EXPONENTIAL1, SOFT_EXPONENTIAL2, SOFT_POWER, SOFT_HYPERBOLIC,
+ SOFT_EXPONENTIAL2REG, SOFT_EXPOENERGY, SOFT_POLYNOMIAL, SOFT_MULTILINEAR) = range(11)
 EQV_ENERGY, EQV_MAZARS = 0, 1
 PLANE_STRAIN, PLANE_STRESS = 0, 1
 AT1, AT2, CZM_LINEAR, CZM_EXPONENTIAL, CZM_CORNELISSEN, CZM_HYPERBOLIC = range(6)
@@ -35,7 +36,8 @@ class Config(C.Structure):
                 ("gc", C.c_double), ("l0", C.c_double), ("sigma_t", C.c_double), ("beta", C.c_double),
                 ("keep_off_diags", C.c_int),
                 ("softening", C.c_int), ("kappa_i", C.c_double), ("kappa_c", C.c_double), ("soft_alpha", C.c_double),
-                ("soft_beta", C.c_double), ("length_scale", C.c_double), ("eqv_strain", C.c_int)]
+                ("soft_beta", C.c_double), ("length_scale", C.c_double), ("eqv_strain", C.c_int),
+                ("soft_b", C.c_double), ("soft_s", C.c_double), ("kappa_p", C.c_double)]
 
 
 class ShapeInfo(C.Structure):
@@ -137,9 +139,10 @@ def ndof_per_node(model, rank):
 
 def make_config(shape, model, material, state=PLANE_STRAIN, young=210e3, poisson=0.3, frac_type=AT2,
                 gc=2.7, l0=0.015, sigma_t=0.0, beta=6500.0, keep_off_diags=0, softening=0, kappa_i=0.0, kappa_c=0.0,
-                soft_alpha=0.0, soft_beta=0.0, length_scale=0.0, eqv_strain=0):
+                soft_alpha=0.0, soft_beta=0.0, length_scale=0.0, eqv_strain=0, soft_b=0.0, soft_s=0.0, kappa_p=0.0):
     return Config(shape, model, material, state, young, poisson, frac_type, gc, l0, sigma_t, beta,
-                  int(keep_off_diags), softening, kappa_i, kappa_c, soft_alpha, soft_beta, length_scale, eqv_strain)
+                  int(keep_off_diags), softening, kappa_i, kappa_c, soft_alpha, soft_beta, length_scale, eqv_strain,
+                  soft_b, soft_s, kappa_p)
 
 
 def psi0(cfg):

@@ -233,7 +233,7 @@ def micro_newton(psi, target, d, frac, alpha):
 
 # ---- GradientDamageModel::getMatrix_ (GradientDamageModel.cpp:368-588) with DamageMaterial (eqvStrain = Energy) ----
 def damage_law(soft, Ki, Kc, al, be, K):
-    """(omega, dOmega/dKappa): DamageMaterial.cpp:1044-1289, laws Perfect, Linear1, Linear2, Exponential1, Exponential2."""
+    """(omega, dOmega/dKappa): DamageMaterial.cpp:1044-1633, numbered like softeningLawDefs (:134-144)."""
     if soft == 0:
         return (0.0 if K < Ki else 1 - Ki / K), (0.0 if K < Ki else Ki / K ** 2)
     if soft == 1:
@@ -244,8 +244,39 @@ def damage_law(soft, Ki, Kc, al, be, K):
     if soft == 3:
         ex = np.exp(-be * (K - Ki))
         return (0.0 if K < Ki else 1 - Ki / K * (1 - al + al * ex)), Ki / K ** 2 * (1 - al + al * ex) + be * Ki / K * al * ex
-    ex = np.exp((Ki - K) / (Kc - Ki))
-    return (0.0 if K < Ki else 1 - Ki / K * ex), Ki / K ** 2 * ex + Ki / K * ex / (Kc - Ki)
+    if soft == 4:
+        ex = np.exp((Ki - K) / (Kc - Ki))
+        return (0.0 if K < Ki else 1 - Ki / K * ex), Ki / K ** 2 * ex + Ki / K * ex / (Kc - Ki)
+    # the laws of :1313-1633; `al` carries the single parameter of hyperbolic (b), expoEnergy (s), multilinear (kappaP)
+    if soft == 5:                                          # power, Kcc = Kc
+        if K > Kc:
+            return (1 - (Ki / Kc) ** be * 0.0 ** al), 0.0
+        om = 1 - (Ki / K) ** be * ((Kc - K) / (Kc - Ki)) ** al
+        c_ = (Kc - K) / (Kc - Ki)
+        d = (Ki / K) ** (be - 1) * c_ ** (al - 1) * (Ki / K ** 2 * be * c_ + Ki / K * al / (Kc - Ki))
+        return (0.0 if K < Ki else om), d
+    if soft == 6:                                          # hyperbolic
+        q = 1 + al * (K - Ki)
+        return (0.0 if K < Ki else 1 - 1 / q), al / q ** 2
+    if soft == 7:                                          # exponential2Reg: absent from the overloads in use
+        return 0.0, 0.0
+    if soft == 8:                                          # expoEnergy
+        if K < Ki:
+            return 0.0, 0.0
+        t = (K - Ki) / Kc
+        return 1 - np.exp(-t ** al), np.exp(-t ** al) * t ** (al - 1) * al / Kc
+    if soft == 9:                                          # polynomial; the derivative's d uses a = Ki - K un-normalised
+        if K < Ki:
+            return 0.0, 0.0
+        an = (K - Ki) / (Kc - Ki)
+        a_ = Ki - K; b_ = Kc - Ki; c_ = a_ / b_; d = 1 + a_ ** 2 * (2 * a_ - 3)
+        return 1 - Ki / K * (1 + an ** 2 * (2 * an - 3)), -Ki / K ** 2 * (2 * K * (c_ / b_ * (2 * c_ - 3) + c_ ** 2 / b_) - d)
+    Kp = al                                                # multilinear
+    if K < Ki:
+        return 0.0, 0.0
+    if K > Kp:
+        return 1 - Ki / K, Ki / K ** 2
+    return (0.0 if K < Kp else (0.999 if K > Kc else (K - Kp) / (Kc - Kp))), (1 / (Kc - Kp) if K < Kc else 0.0)
 
 
 def element_gd(x, N, dN, w, u, eqv, kap0, load0, D0, law, c, want_K=True, mazars=None):

@@ -17,7 +17,25 @@ LAWS = {po.SOFT_PERFECT: dict(kappa_i=1.0e-3),
         po.SOFT_LINEAR1: dict(kappa_i=1.0e-3, kappa_c=4.0e-3),
         po.SOFT_LINEAR2: dict(kappa_i=1.0e-3, kappa_c=4.0e-3),
         po.SOFT_EXPONENTIAL1: dict(kappa_i=1.0e-3, soft_alpha=0.95, soft_beta=300.0),
-        po.SOFT_EXPONENTIAL2: dict(kappa_i=1.0e-3, kappa_c=6.0e-3)}
+        po.SOFT_EXPONENTIAL2: dict(kappa_i=1.0e-3, kappa_c=6.0e-3),
+        po.SOFT_POWER: dict(kappa_i=1.0e-3, kappa_c=6.5e-3, soft_alpha=1.5, soft_beta=0.8),
+        po.SOFT_HYPERBOLIC: dict(kappa_i=1.0e-3, soft_b=400.0),
+        po.SOFT_EXPONENTIAL2REG: dict(kappa_i=1.0e-3),
+        po.SOFT_EXPOENERGY: dict(kappa_i=1.0e-3, kappa_c=3.0e-3, soft_s=1.5),
+        po.SOFT_POLYNOMIAL: dict(kappa_i=1.0e-3, kappa_c=8.0e-3),
+        po.SOFT_MULTILINEAR: dict(kappa_i=1.0e-3, kappa_p=2.5e-3, kappa_c=5.0e-3)}
+# laws whose getDeriv... really is d omega / d kappa: the polynomial law builds one factor from an un-normalised
+# difference (DamageMaterial.cpp:1566-1569), the multilinear one pairs omega = 0 with the slope of its second branch below
+# kappaP (:1594-1601, :1624-1631), exponential2Reg never reaches a law (:802-851); all three are restated as they stand
+CONSISTENT = (po.SOFT_PERFECT, po.SOFT_LINEAR1, po.SOFT_LINEAR2, po.SOFT_EXPONENTIAL1, po.SOFT_EXPONENTIAL2, po.SOFT_POWER,
+              po.SOFT_HYPERBOLIC, po.SOFT_EXPOENERGY)
+
+
+def law_tuple(soft):
+    """(soft, kappaI, kappaC, alpha | b | s | kappaP, beta) as tests/np_ref.py takes it."""
+    kw = LAWS[soft]
+    one = kw.get("soft_alpha", kw.get("soft_b", kw.get("soft_s", kw.get("kappa_p", 0.0))))
+    return (soft, kw["kappa_i"], kw.get("kappa_c", 0.0), one, kw.get("soft_beta", 0.0))
 
 
 def gd_config(shape, soft, state2d=po.PLANE_STRAIN, c=0.02, eqv=po.EQV_ENERGY):
@@ -49,8 +67,7 @@ def test_softening_laws_closed_form_and_derivative():
     st = np.zeros(12)
     for soft, kw in LAWS.items():
         cfg = gd_config(po.QUAD4_G2, soft)
-        Ki, Kc = kw["kappa_i"], kw.get("kappa_c", 0.0)
-        al, be = kw.get("soft_alpha", 0.0), kw.get("soft_beta", 0.0)
+        _, Ki, Kc, al, be = law_tuple(soft)
         for kap in (0.5e-3, 1.0e-3, 2.0e-3, 3.9e-3, 7.0e-3):
             st[2::3] = kap                                            # uniform nonlocal strain above the old kappa = 0
             out = po.assemble(cfg, coords, conn, rp, ci, st)
@@ -62,12 +79,18 @@ def test_softening_laws_closed_form_and_derivative():
                   po.SOFT_LINEAR1: 0.999 if kap > Kc else Kc * (kap - Ki) / (kap * (Kc - Ki)),
                   po.SOFT_LINEAR2: 0.999 if kap > Kc else (kap - Ki) / (Kc - Ki),
                   po.SOFT_EXPONENTIAL1: 1 - Ki / kap * (1 - al + al * np.exp(-be * (kap - Ki))),
-                  po.SOFT_EXPONENTIAL2: 1 - Ki / kap * np.exp((Ki - kap) / (Kc - Ki) if Kc else 0.0)}[soft]
+                  po.SOFT_EXPONENTIAL2: 1 - Ki / kap * np.exp((Ki - kap) / (Kc - Ki) if Kc else 0.0),
+                  po.SOFT_POWER: 1.0 if kap > Kc else 1 - (Ki / kap) ** be * ((Kc - kap) / (Kc - Ki)) ** al if Kc else 0.0,
+                  po.SOFT_HYPERBOLIC: 1 - 1 / (1 + al * (kap - Ki)),
+                  po.SOFT_EXPONENTIAL2REG: 0.0,
+                  po.SOFT_EXPOENERGY: 1 - np.exp(-(max(kap - Ki, 0.0) / Kc) ** al) if Kc else 0.0,
+                  po.SOFT_POLYNOMIAL: 1 - Ki / kap * (1 + ((kap - Ki) / (Kc - Ki)) ** 2 * (2 * (kap - Ki) / (Kc - Ki) - 3)) if Kc else 0.0,
+                  po.SOFT_MULTILINEAR: 1 - Ki / kap if kap > al else 0.0}[soft]
             if kap < Ki:
                 om = 0.0
             assert np.allclose(K[np.ix_(ud, ud)], (1 - om) * Kel, rtol=1e-13, atol=1e-13 * np.abs(Kel).max()), (soft, kap)
             assert np.allclose(out["hist_new"], kap if kap < Ki else -kap)        # loading flag once kappa >= kappaI
-            if abs(kap - Ki) > 1e-6 and (not Kc or abs(kap - Kc) > 2e-4):
+            if soft in CONSISTENT and abs(kap - Ki) > 1e-6 and (not Kc or abs(kap - Kc) > 2e-4):
                 h = 1e-8
                 fd = (np_ref.damage_law(soft, Ki, Kc, al, be, kap + h)[0] - np_ref.damage_law(soft, Ki, Kc, al, be, kap - h)[0]) / (2 * h)
                 an = np_ref.damage_law(soft, Ki, Kc, al, be, kap)[1]
@@ -125,7 +148,10 @@ def test_uniaxial_element_closed_form():
     (po.QUAD8_G3, po.SOFT_LINEAR2, po.EQV_ENERGY, po.PLANE_STRAIN), (po.TRI6_G3, po.SOFT_EXPONENTIAL2, po.EQV_ENERGY, po.PLANE_STRAIN),
     (po.TRI3_G1, po.SOFT_EXPONENTIAL1, po.EQV_MAZARS, po.PLANE_STRESS),      # the material of the reference's tests/sm03
     (po.QUAD4_G2, po.SOFT_EXPONENTIAL2, po.EQV_MAZARS, po.PLANE_STRAIN), (po.HEX8_G2, po.SOFT_LINEAR1, po.EQV_MAZARS, po.PLANE_STRAIN),
-    (po.QUAD8_G3, po.SOFT_EXPONENTIAL1, po.EQV_MAZARS, po.PLANE_STRESS)])
+    (po.QUAD8_G3, po.SOFT_EXPONENTIAL1, po.EQV_MAZARS, po.PLANE_STRESS),
+    (po.QUAD4_G2, po.SOFT_POWER, po.EQV_ENERGY, po.PLANE_STRAIN), (po.TRI3_G1, po.SOFT_HYPERBOLIC, po.EQV_MAZARS, po.PLANE_STRESS),
+    (po.QUAD4_G2, po.SOFT_EXPONENTIAL2REG, po.EQV_ENERGY, po.PLANE_STRAIN), (po.HEX8_G2, po.SOFT_EXPOENERGY, po.EQV_ENERGY, po.PLANE_STRAIN),
+    (po.TRI6_G3, po.SOFT_POLYNOMIAL, po.EQV_ENERGY, po.PLANE_STRESS), (po.QUAD4_G2, po.SOFT_MULTILINEAR, po.EQV_MAZARS, po.PLANE_STRAIN)])
 def test_oracle_vs_numpy_restatement(shape, soft, eqv, state2d):
     rank, npe, nip, _ = po.shape_info(shape)
     coords, conn = GRID[shape]()
@@ -139,8 +165,7 @@ def test_oracle_vs_numpy_restatement(shape, soft, eqv, state2d):
     N, dN, w = po.shape_tables(shape)
     D0 = np_ref.hooke(rank, state2d, E, NU)
     maz = (NU, state2d == po.PLANE_STRESS) if eqv == po.EQV_MAZARS else None
-    kw = LAWS[soft]
-    law = (soft, kw["kappa_i"], kw.get("kappa_c", 0.0), kw.get("soft_alpha", 0.0), kw.get("soft_beta", 0.0))
+    law = law_tuple(soft)
     ndof = nn * nd
     K = np.zeros((ndof, ndof)); f = np.zeros(ndof); Hn = np.zeros_like(H0)
     S = st.reshape(nn, nd)
@@ -248,7 +273,14 @@ GPU_MESH = {po.TRI3_G1: lambda: meshgen.grid_tri3(9, 7), po.QUAD4_G2: lambda: me
     (po.TRI3_G1, po.SOFT_EXPONENTIAL1, po.PLANE_STRESS, 1),                   # the material of the reference's tests/sm03
     (po.QUAD4_G2, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN, 1), (po.QUAD4_G2, po.SOFT_LINEAR1, po.PLANE_STRESS, 1),
     (po.HEX8_G2, po.SOFT_LINEAR1, po.PLANE_STRAIN, 1), (po.QUAD8_G3, po.SOFT_EXPONENTIAL1, po.PLANE_STRESS, 1),
-    (po.TRI6_G3, po.SOFT_PERFECT, po.PLANE_STRAIN, 1), (po.HEX20_G2, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN, 1)])
+    (po.TRI6_G3, po.SOFT_PERFECT, po.PLANE_STRAIN, 1), (po.HEX20_G2, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN, 1),
+    # the laws of DamageMaterial.cpp:1313-1633
+    (po.QUAD4_G2, po.SOFT_POWER, po.PLANE_STRAIN, 0), (po.HEX8_G2, po.SOFT_POWER, po.PLANE_STRAIN, 1),
+    (po.TRI3_G1, po.SOFT_HYPERBOLIC, po.PLANE_STRESS, 1), (po.HEX8_G2, po.SOFT_HYPERBOLIC, po.PLANE_STRAIN, 0),
+    (po.QUAD4_G2, po.SOFT_EXPONENTIAL2REG, po.PLANE_STRAIN, 0), (po.QUAD4_G2, po.SOFT_EXPOENERGY, po.PLANE_STRESS, 1),
+    (po.QUAD8_G3, po.SOFT_EXPOENERGY, po.PLANE_STRAIN, 0), (po.TRI6_G3, po.SOFT_POLYNOMIAL, po.PLANE_STRAIN, 0),
+    (po.HEX8_G2, po.SOFT_POLYNOMIAL, po.PLANE_STRAIN, 1), (po.QUAD4_G2, po.SOFT_MULTILINEAR, po.PLANE_STRAIN, 1),
+    (po.HEX20_G2, po.SOFT_MULTILINEAR, po.PLANE_STRAIN, 0)])
 def test_gpu_gradient_damage_parity(shape, soft, state2d, eqv):
     """K + f pass, commit, K + f pass on the unchanged state (the f == 0 branch), then a force-only pass, each against
     the oracle carrying its own history the same way."""

@@ -274,3 +274,45 @@ def test_sm03_gradient_damage_through_take_action():
     r3 = po.assemble(cfg, coords, conn, rp, ci, st3, hist_pre=r1["hist_new"], want_K=False)
     assert ok and np.abs(f3 - r3["f"]).max() < 1e-12 * np.abs(r3["f"]).max()
     assert case.take_action("setStepSize", step=0.5, step0=0.25)[0] is False
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,props,kw", [
+    ("power", "kappaC = 0.0009; alpha = 1.5; beta = 0.8;", dict(kappa_c=9e-4, soft_alpha=1.5, soft_beta=0.8)),
+    ("hyperbolic", "b = 4000.;", dict(soft_b=4000.0)),
+    ("exponential2Reg", "", dict()),
+    ("expoEnergy", "kappaC = 0.0002; s = 1.5;", dict(kappa_c=2e-4, soft_s=1.5)),
+    ("polynomial", "kappaC = 0.0009;", dict(kappa_c=9e-4)),
+    ("multilinear", "kappaP = 0.00012; kappaC = 0.0004;", dict(kappa_p=1.2e-4, kappa_c=4e-4))])
+def test_sm03_with_the_other_softening_laws(name, props, kw):
+    """DamageMaterial::configure's law-specific properties (DamageMaterial.cpp:210-273) through the mirror: a missing one
+    is an error as in Jem's props.get, a complete set assembles what the oracle assembles."""
+    from oracle import pyoracle as po
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sm03")
+    pro = open(os.path.join(g, "model.pro")).read(); mesh = open(os.path.join(g, "problem.mesh")).read()
+    base = pro.replace('"exponential1"', '"%s"' % name).replace("alpha = 0.92; beta = 300.;", "%s")
+    assert base != pro
+    if props:
+        with pytest.raises(hostapi.HostError):
+            hostapi.Case(base % "", mesh)
+    case = hostapi.Case(base % props, mesh)
+    nodes, elems, groups = _read_mesh(mesh)
+    ids = sorted(nodes)
+    coords = np.array([nodes[i][:2] for i in ids])
+    conn = np.array([[n - 1 for n in elems[e]] for e in groups["bulk"]], dtype=np.int32)
+    nn = len(ids)
+    rp, ci = case.pattern()
+    law = dict(zip(("power", "hyperbolic", "exponential2Reg", "expoEnergy", "polynomial", "multilinear"),
+                   (po.SOFT_POWER, po.SOFT_HYPERBOLIC, po.SOFT_EXPONENTIAL2REG, po.SOFT_EXPOENERGY, po.SOFT_POLYNOMIAL,
+                    po.SOFT_MULTILINEAR)))[name]
+    cfg = po.make_config(po.TRI3_G1, po.GRADIENT_DAMAGE, po.DAMAGE, state=po.PLANE_STRESS, young=40.e3, poisson=0.2,
+                         softening=law, kappa_i=0.000075, length_scale=1.0, eqv_strain=po.EQV_MAZARS, **kw)
+    x, y = coords[:, 0], coords[:, 1]
+    st = np.zeros(3 * nn)
+    st[0::3] = 2e-4 * (y - 50.0) * np.sin(np.pi * x / 500.0) * 0.02
+    st[1::3] = -3e-3 * np.sin(np.pi * x / 500.0)
+    st[2::3] = 1.2e-4 * np.exp(-((x - 250.0) / 60.0) ** 2) * (1.0 - y / 130.0) + 1e-5
+    ok, K, f = case.take_action("GET_MATRIX0", state=st)
+    r = po.assemble(cfg, coords, conn, rp, ci, st)
+    assert ok and (r["hist_new"] < 0).sum() > 20
+    assert np.abs(K - r["K"]).max() < 1e-12 * np.abs(r["K"]).max() and np.abs(f - r["f"]).max() < 1e-12 * np.abs(r["f"]).max()
