@@ -18,7 +18,7 @@ TRI3_G1, TRI3_G3, QUAD4_G2, QUAD8_G3, QUAD8_G2, TRI6_G3, HEX8_G2, HEX20_G3, HEX2
 HOOKE, AMOR_PHASE, BOURDIN_PHASE, MIEHE_PHASE, DAMAGE = range(5)
 (SOFT_PERFECT, SOFT_LINEAR1, SOFT_LINEAR2, SOFT_EXPONENTIAL1, SOFT_EXPONENTIAL2, SOFT_POWER, SOFT_HYPERBOLIC,
  SOFT_EXPONENTIAL2REG, SOFT_EXPOENERGY, SOFT_POLYNOMIAL, SOFT_MULTILINEAR) = range(11)
-EQV_ENERGY, EQV_MAZARS = 0, 1
+EQV_ENERGY, EQV_MAZARS, EQV_VONMISES = 0, 1, 2
 PLANE_STRAIN, PLANE_STRESS = 0, 1
 AT1, AT2, CZM_LINEAR, CZM_EXPONENTIAL, CZM_CORNELISSEN, CZM_HYPERBOLIC = range(6)
 PATTERN_FULL, PATTERN_WRITTEN = 0, 1
@@ -45,7 +45,7 @@ class Problem(C.Structure):
                 ("ndof", C.c_int64), ("pattern_kind", C.c_int32), ("device", C.c_int32),
                 ("softening", C.c_int32), ("kappa_i", C.c_double), ("kappa_c", C.c_double), ("soft_alpha", C.c_double),
                 ("soft_beta", C.c_double), ("length_scale", C.c_double), ("eqv_strain", C.c_int32),
-                ("soft_b", C.c_double), ("soft_s", C.c_double), ("kappa_p", C.c_double)]
+                ("soft_b", C.c_double), ("soft_s", C.c_double), ("kappa_p", C.c_double), ("eta", C.c_double)]
 
 
 class AssembleArgs(C.Structure):
@@ -151,7 +151,7 @@ class Assembler:
                  frac_type=AT2, gc=2.7, l0=0.015, sigma_t=0.0, beta=6500.0, keep_off_diags=False,
                  row_ptr=None, col_idx=None, node_dofs=None, ndof=0, pattern_kind=PATTERN_FULL, device=0,
                  softening=0, kappa_i=0.0, kappa_c=0.0, soft_alpha=0.0, soft_beta=0.0, length_scale=0.0, eqv_strain=0,
-                 soft_b=0.0, soft_s=0.0, kappa_p=0.0):
+                 soft_b=0.0, soft_s=0.0, kappa_p=0.0, eta=0.0):
         coords = np.ascontiguousarray(coords, dtype=np.float64)
         conn = np.ascontiguousarray(conn, dtype=np.int32)
         rank, npe, nip = SHAPE_INFO[shape]
@@ -170,7 +170,7 @@ class Assembler:
                     int(bool(keep_off_diags)), coords.shape[0], _np_ptr(coords), conn.shape[0], _np_ptr(conn),
                     _np_ptr(row_ptr), _np_ptr(col_idx), _np_ptr(node_dofs), ndof, pattern_kind, device,
                     softening, kappa_i, kappa_c, soft_alpha, soft_beta, length_scale, eqv_strain,
-                    soft_b, soft_s, kappa_p)
+                    soft_b, soft_s, kappa_p, eta)
         self.h = C.c_void_p()
         _check(lib().fa_create(C.byref(p), C.byref(self.h)))
         L = lib()

@@ -426,8 +426,14 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     if (p->softening < FA_SOFT_PERFECT || p->softening > FA_SOFT_MULTILINEAR)
       return fail(FA_ERR_ARG, "unexpected definition of softening law!!! (0 ... 10, the order of DamageMaterial's softeningLawDefs)");
     if (!(p->kappa_i > 0.0)) return fail(FA_ERR_ARG, "Damage: kappaI (or ft / young) must be positive");
-    if (p->eqv_strain != FA_EQV_ENERGY && p->eqv_strain != FA_EQV_MAZARS)
-      return fail(FA_ERR_ARG, "unexpected definition of equivalent strain!!! Available here: Energy, Mazars");
+    if (p->eqv_strain < FA_EQV_ENERGY || p->eqv_strain > FA_EQV_VONMISES)
+      return fail(FA_ERR_ARG, "unexpected definition of equivalent strain!!! Available ones are: Mazars, vonMises, Energy");
+    if (p->eqv_strain == FA_EQV_VONMISES) {
+      // DamageMaterial.cpp:677-683 returns a 6-vector whatever the strain size; GradientDamageModel.cpp:548 multiplies it
+      // with a 4-row B matrix in 2-D
+      if (sh.rank != 3) return fail(FA_ERR_UNSUPPORTED, "eqvStrain = vonMises is available for 3-D shapes only");
+      if (!(p->eta > 0.0)) return fail(FA_ERR_ARG, "eqvStrain = vonMises needs eta > 0");
+    }
     const int sl = p->softening;
     if ((sl == FA_SOFT_LINEAR1 || sl == FA_SOFT_LINEAR2 || sl == FA_SOFT_EXPONENTIAL2 || sl == FA_SOFT_POWER || sl == FA_SOFT_POLYNOMIAL) &&
         !(p->kappa_c > p->kappa_i))
@@ -502,6 +508,10 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     if (p->softening == FA_SOFT_MULTILINEAR) P.sA = p->kappa_p;
     P.eqv = p->eqv_strain; P.k2sig = (p->eqv_strain != FA_EQV_ENERGY) ? 1 : 0;
     P.pstress = (sh.rank == 2 && p->state == FA_PLANE_STRESS) ? 1 : 0; P.poiD = p->poisson / (p->poisson - 1.0);
+    if (p->eqv_strain == FA_EQV_VONMISES) {             // VonMisesStrain::init (eta_, elasticMat_->getPoisson ()), :310
+      const double k = p->eta, nu = p->poisson;
+      P.vmA = (k - 1.0) / (1.0 - 2.0 * nu); P.vmB = 0.5 / k; P.vmC = 12.0 * k / (1.0 + 2.0 * nu + nu * nu);
+    }
   }
 
   // ---- inverse connectivity, element-ascending per node ----

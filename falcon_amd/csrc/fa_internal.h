@@ -171,9 +171,10 @@ struct Params {
   double eta, a1, a2, a3, psi0, beta, dt, dt0;
   double alpha;              // micromorphic penalty beta * gc / l0 (MicroPhaseFractureModel.cpp:579)
   // gradient damage (model 7): softening law and its parameters (DamageMaterial.cpp:157-268); c2 holds the length scale c
-  int32_t soft, eqv;         // softening law, equivalent strain (0 Energy, 1 Mazars)
+  int32_t soft, eqv;         // softening law, equivalent strain (0 Energy, 1 Mazars, 2 vonMises)
   int32_t k2sig, pstress;    // K2 from the stress record (sig / (1 - omega) = D0 eps) because sp holds d eq / d eps; plane stress
   double kI, kC, sA, sB, poiD;   // poiD = nu / (nu - 1) (DamageMaterial.cpp:971)
+  double vmA, vmB, vmC;          // VonMisesStrain::init (VonMisesStrain.cpp:34-43)
 };
 
 // launchers, one translation unit per shape (fa_kernels_<shape>.hip)

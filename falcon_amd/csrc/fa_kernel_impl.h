@@ -448,6 +448,25 @@ __device__ __forceinline__ void Bt_vec(const double (&ga)[RANK], const double (&
   }
 }
 
+// von Mises equivalent strain (DamageMaterial.cpp:609-617, :667-684; VonMisesStrain.cpp:49-116; J2 and its gradient with
+// respect to the tensor components, Invariants.cpp:111-118, :188-202).  3-D only.
+template <int S>
+__device__ __forceinline__ void vonmises_strain(const Params& P, const double (&eps)[S], double& eq, double (&deq)[S]) {
+  if constexpr (S == 6) {
+    const double v0 = eps[0], v1 = eps[1], v2 = eps[2], v3 = 0.5 * eps[3], v4 = 0.5 * eps[4], v5 = 0.5 * eps[5];
+    const double I1 = v0 + v1 + v2;
+    const double J2 = (1.0 / 3.0) * (v0 * v0 + v1 * v1 + v2 * v2 - v0 * v1 - v1 * v2 - v2 * v0) + v3 * v3 + v4 * v4 + v5 * v5;
+    double d = sqrt(P.vmA * P.vmA * I1 * I1 + P.vmC * J2);
+    eq = P.vmB * (P.vmA * I1 + d);
+    if (d == 0.0) d = 1.0;
+    const double e = P.vmB / d, dI1 = P.vmA * P.vmB + e * P.vmA * P.vmA * I1, dJ2 = e * P.vmC * 0.5;
+    deq[0] = dI1 + dJ2 * ((1.0 / 3.0) * (2.0 * v0 - v1 - v2));
+    deq[1] = dI1 + dJ2 * ((1.0 / 3.0) * (2.0 * v1 - v2 - v0));
+    deq[2] = dI1 + dJ2 * ((1.0 / 3.0) * (2.0 * v2 - v0 - v1));
+    deq[3] = dJ2 * (2.0 * v3); deq[4] = dJ2 * (2.0 * v4); deq[5] = dJ2 * (2.0 * v5);
+  }
+}
+
 // Mazars equivalent strain and its derivative as DamageMaterial computes them (DamageMaterial.cpp:618-642, :886-1032):
 // principal strains from the trigonometric solution of the characteristic cubic (Invariants.cpp:209-224,
 // MathUtils.cpp:150-181) with the reference's PI = 3.14159265 (Constants.cpp:13).  eps: xx, yy, gamma_xy in 2-D (zz = 0).
@@ -616,6 +635,7 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
 #pragma unroll
         for (int i = 0; i < S; i++) deq[i] = e0v[i];
         if (P.eqv == 1) mazars_strain<RANK, S>(P, eps, eq, deq);
+        else if (P.eqv == 2) vonmises_strain<S>(P, eps, eq, deq);
         const double kappa0 = fabs(H0);
         const int load0 = (H0 < 0.0) ? 1 : 0;
         const double fl = pf - kappa0;                    // loading function (:383)

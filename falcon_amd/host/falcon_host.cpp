@@ -478,9 +478,14 @@ class SolidAssemblyModel : public Model {
     std::string eq; props.get(eq, "eqvStrain");
     if (eq == "Mazars") eqvStrain_ = FA_EQV_MAZARS;
     else if (eq == "Energy") eqvStrain_ = FA_EQV_ENERGY;
-    else if (eq == "vonMises")
-      throw Error(props.context, "eqvStrain = vonMises is not available on the GPU assembly path (its derivative is a 6-vector for "
-                                 "2-D strains in the reference, DamageMaterial.cpp:677-683)");
+    else if (eq == "vonMises") {
+      if (rank_ != 3)
+        throw Error(props.context, "eqvStrain = vonMises is not available on the GPU assembly path for 2-D models (its derivative is a "
+                                   "6-vector for 2-D strains in the reference, DamageMaterial.cpp:677-683)");
+      props.get(eta_, "eta");                                                                                          // :295-300
+      if (eta_ < 0) throw Error(props.context, "property `eta' out of range");
+      eqvStrain_ = FA_EQV_VONMISES;
+    }
     else throw Error("DamageMaterial::configure", "unexpected definition of equivalent strain!!!\nAvailable ones are: Mazars, vonMises, Energy");
   }
 
@@ -558,7 +563,7 @@ class SolidAssemblyModel : public Model {
     p.young = young_; p.poisson = poisson_; p.frac_type = fracType_ < 0 ? FA_AT2 : fracType_;
     p.gc = gc_; p.l0 = l0_; p.sigma_t = sigmaT_; p.beta = beta_; p.keep_off_diags = keepOffDiags_ ? 1 : 0;
     p.softening = softening_; p.kappa_i = kappaI_; p.kappa_c = kappaC_; p.soft_alpha = softAlpha_; p.soft_beta = softBeta_;
-    p.soft_b = softB_; p.soft_s = softS_; p.kappa_p = kappaP_;
+    p.soft_b = softB_; p.soft_s = softS_; p.kappa_p = kappaP_; p.eta = eta_;
     p.length_scale = lengthScale_; p.eqv_strain = eqvStrain_;
     p.nnode = (int64_t)nodes_.size(); p.coords = xc.data();
     p.nel = (int64_t)ielems_.size(); p.conn = conn.data();
@@ -642,7 +647,7 @@ class SolidAssemblyModel : public Model {
   double gc_ = 2.7, l0_ = 0.015, sigmaT_ = 0.0, beta_ = 6500.0;   // PhaseFractureModel.cpp:253-263, Ext :247
   double dt_ = 0.0, dt0_ = 0.0, errExt_ = 0.0;
   int softening_ = 0, eqvStrain_ = 0;                         // DamageMaterial (GradientDamage)
-  double kappaI_ = 0.0, kappaC_ = 0.0, softAlpha_ = 0.0, softBeta_ = 0.0, lengthScale_ = 0.0, softB_ = 0.0, softS_ = 0.0, kappaP_ = 0.0;
+  double kappaI_ = 0.0, kappaC_ = 0.0, softAlpha_ = 0.0, softBeta_ = 0.0, lengthScale_ = 0.0, softB_ = 0.0, softS_ = 0.0, kappaP_ = 0.0, eta_ = 0.0;
   bool extFail_ = false; int oIter_ = 0, oMaxIter_ = 5000; double oTol_ = 1.e-3;
   std::vector<double> stateExt_;
   fa_ctx* ctx_ = nullptr;

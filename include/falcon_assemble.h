@@ -49,11 +49,12 @@ enum { FA_LINEAR_ELASTICITY = 0, FA_PHASE_FRACTURE = 1, FA_PHASE_FRACTURE_EXT = 
 enum { FA_HOOKE = 0, FA_AMOR_PHASE = 1, FA_BOURDIN_PHASE = 2, FA_MIEHE_PHASE = 3,
        FA_DAMAGE = 4 /* "Damage", src/materials/DamageMaterial.cpp, with eqvStrain = "Energy" (:644-649, :698-703) or
                         "Mazars" (:618-642, :886-1032; principal strains from the reference's trigonometric cubic solve
-                        with its PI = 3.14159265).  "vonMises" is refused: its derivative is a 6-vector for 2-D strains
-                        (:677-683), used out of bounds at GradientDamageModel.cpp:548 */ };
+                        with its PI = 3.14159265) or, for 3-D shapes, "vonMises" (:609-617, :667-684, VonMisesStrain.cpp).
+                        "vonMises" is refused in 2-D: its derivative is a 6-vector whatever the strain size (:677-683),
+                        used out of bounds at GradientDamageModel.cpp:548 */ };
 
 /* eqvStrain of the Damage material */
-enum { FA_EQV_ENERGY = 0, FA_EQV_MAZARS = 1 };
+enum { FA_EQV_ENERGY = 0, FA_EQV_MAZARS = 1, FA_EQV_VONMISES = 2 /* 3-D shapes only, needs eta */ };
 
 /* softening (DamageMaterial.cpp:182-273; the laws are the free functions of :1044-1633), numbered like
  * softeningLawDefs (:134-144).  "exponential2Reg" is accepted by the reference but absent from the damageEvolution_ /
@@ -116,8 +117,9 @@ typedef struct {
    * ft / young), kappaC, alpha, beta, and the gradient parameter c = lengthScale (GradientDamageModel.cpp:438) */
   int32_t softening;
   double  kappa_i, kappa_c, soft_alpha, soft_beta, length_scale;
-  int32_t eqv_strain;                          /* FA_EQV_ENERGY / FA_EQV_MAZARS (eqvStrain, DamageMaterial.cpp:275-308) */
+  int32_t eqv_strain;                          /* FA_EQV_* (eqvStrain, DamageMaterial.cpp:275-308) */
   double  soft_b, soft_s, kappa_p;             /* hyperbolic "b" (:237), expoEnergy "s" (:257), multilinear "kappaP" (:271) */
+  double  eta;                                 /* FA_EQV_VONMISES: "eta" (:297), compressive / tensile strength */
 } fa_problem;
 
 typedef struct {

@@ -994,6 +994,41 @@ static void mazars_deriv(const fo_config* c, int rank, const double* strain, dou
   ret[3] = dedprin0 * de1dexy + dedprin1 * de2dexy;
 }
 
+/* ---- von Mises equivalent strain (DamageMaterial.cpp:609-617, :667-684 with VonMisesStrain.cpp:34-116 and
+ * Invariants::getJ2 / getGradI1 / getGradJ2, Invariants.cpp:111-202).  Rank 3 only: for a 4-component strain the
+ * reference assigns the 6-vector of :683 to a 4-vector.  The gradient is the one with respect to the tensor components
+ * (2 v6[3] = gamma_xy for the shear entries), as the reference returns it. ---- */
+static void vonmises_abc(const fo_config* cfg, double* a, double* b, double* c) {       /* VonMisesStrain::init */
+  const double k = cfg->eta, nu = cfg->poisson;
+  *a = (k - 1.0) / (1.0 - 2.0 * nu); *b = 0.5 / k; *c = 12.0 * k / (1.0 + 2.0 * nu + nu * nu);
+}
+static double inv_J2(const double* v) {
+  return (1.0 / 3.0) * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2] - v[0] * v[1] - v[1] * v[2] - v[2] * v[0]) +
+         v[3] * v[3] + v[4] * v[4] + v[5] * v[5];
+}
+static double vonmises_eq(const fo_config* cfg, int rank, const double* strain) {
+  double v[6], a, b, c;
+  strain_v6(rank, strain, v); vonmises_abc(cfg, &a, &b, &c);
+  const double I1 = inv_I1(v), J2 = inv_J2(v);
+  return b * (a * I1 + sqrt(a * a * I1 * I1 + c * J2));
+}
+static void vonmises_deriv(const fo_config* cfg, int rank, const double* strain, double* ret) {
+  double v[6], a, b, c;
+  strain_v6(rank, strain, v); vonmises_abc(cfg, &a, &b, &c);
+  const double I1 = inv_I1(v), J2 = inv_J2(v);
+  double d = sqrt(a * a * I1 * I1 + c * J2);
+  if (d == 0.0) d = 1.0;
+  const double e = b / d, deqdI1 = a * b + e * a * a * I1, deqdJ2 = e * c * 0.5;
+  const double gJ2[6] = { (1.0 / 3.0) * (2.0 * v[0] - v[1] - v[2]), (1.0 / 3.0) * (2.0 * v[1] - v[2] - v[0]),
+                          (1.0 / 3.0) * (2.0 * v[2] - v[0] - v[1]), 2.0 * v[3], 2.0 * v[4], 2.0 * v[5] };
+  for (int i = 0; i < 6; i++) ret[i] = deqdI1 * (i < 3 ? 1.0 : 0.0) + deqdJ2 * gJ2[i];
+}
+int fo_vonmises(const fo_config* cfg, const double* strain6, double* eq, double* deriv) {   /* test hook */
+  *eq = vonmises_eq(cfg, 3, strain6);
+  vonmises_deriv(cfg, 3, strain6, deriv);
+  return 0;
+}
+
 /* test hook: Mazars equivalent strain, its derivative and the principal values of a STRAIN_COUNTS[rank] strain vector */
 int fo_mazars(const fo_config* cfg, int rank, const double* strain, double* eq, double* deriv, double* princ) {
   if (rank != 2 && rank != 3) FAIL("rank %d", rank);
@@ -1013,7 +1048,11 @@ static int assemble_gd(const fo_config* cfg, const double* coords, const int32_t
   shape_t sh;
   if (shape_init(&sh, cfg->shape)) return -1;
   if (cfg->material != FO_DAMAGE) FAIL("GradientDamage needs the Damage material");
-  if (cfg->eqv_strain != FO_EQV_ENERGY && cfg->eqv_strain != FO_EQV_MAZARS) FAIL("unexpected definition of equivalent strain!!! Restated here: Energy, Mazars");
+  if (cfg->eqv_strain < FO_EQV_ENERGY || cfg->eqv_strain > FO_EQV_VONMISES) FAIL("unexpected definition of equivalent strain!!!");
+  if (cfg->eqv_strain == FO_EQV_VONMISES) {
+    if (sh.rank != 3) FAIL("eqvStrain = vonMises: rank 3 only (DamageMaterial.cpp:677-683 returns a 6-vector)");
+    if (!(cfg->eta > 0.0)) FAIL("eqvStrain = vonMises needs eta > 0");
+  }
   const int rank = sh.rank, nodeCount = sh.npe, ipCount = sh.nip;
   const int strCount = STRAIN_COUNTS[rank];
   const int dispCount = nodeCount * rank, eqvCount = nodeCount, ndofpn = rank + 1, srows = strCount + 1;
@@ -1074,6 +1113,7 @@ static int assemble_gd(const fo_config* cfg, const double* coords, const int32_t
       const double wip = ipWeights[ip];
       matvec(strCount, stiff0, strain, d0e);                              /* stiff0 eps (:557); = dEpsBardEps for Energy, :700-705 */
       if (cfg->eqv_strain == FO_EQV_MAZARS) mazars_deriv(cfg, rank, strain, deq);   /* getdEpsBardEps (:546) */
+      else if (cfg->eqv_strain == FO_EQV_VONMISES) vonmises_deriv(cfg, rank, strain, deq);
       else for (int cc = 0; cc < strCount; cc++) deq[cc] = d0e[cc];
       if (mbuilder) {
         for (int cc = 0; cc < strCount; cc++) for (int j = 0; j < dispCount; j++) {      /* elemMat1 += wip bdt stiff bd */
@@ -1106,6 +1146,7 @@ static int assemble_gd(const fo_config* cfg, const double* coords, const int32_t
         elemMat4[a * eqvCount + b] += wip * (Nip[a] * Nip[b] + c * s);
       }
       const double equiStrain = (cfg->eqv_strain == FO_EQV_MAZARS) ? mazars_eq(rank, strain)
+                              : (cfg->eqv_strain == FO_EQV_VONMISES) ? vonmises_eq(cfg, rank, strain)
                                                                     : 0.5 * dotn(strCount, strain, d0e);   /* getEquiStrain (:602-652) */
       for (int i = 0; i < dispCount; i++) {
         double s = 0.0;

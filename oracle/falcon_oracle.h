@@ -60,7 +60,7 @@ enum { FO_SOFT_PERFECT = 0, FO_SOFT_LINEAR1 = 1, FO_SOFT_LINEAR2 = 2, FO_SOFT_EX
 
 /* DamageMaterial equivalent strains restated: "Energy" (:644-649, :698-703) and "Mazars" (:618-642, :886-1032); the
  * vonMises one returns a 6-vector for 2-D strains (:677-683) whose use in GradientDamageModel.cpp:548 is out of bounds */
-enum { FO_EQV_ENERGY = 0, FO_EQV_MAZARS = 1 };
+enum { FO_EQV_ENERGY = 0, FO_EQV_MAZARS = 1, FO_EQV_VONMISES = 2 /* rank 3 only */ };
 
 /* 2D problem state (HookeMaterial.cpp:92-103) */
 enum { FO_PLANE_STRAIN = 0, FO_PLANE_STRESS = 1 };
@@ -87,6 +87,7 @@ typedef struct {
   double kappa_i, kappa_c, soft_alpha, soft_beta, length_scale;
   int    eqv_strain;     /* FO_EQV_ENERGY / FO_EQV_MAZARS (DamageMaterial.cpp:275-308) */
   double soft_b, soft_s, kappa_p;   /* hyperbolic b (:237), expoEnergy s (:257), multilinear kappaP (:271) */
+  double eta;            /* vonMises: ratio of compressive to tensile strength (:297) */
 } fo_config;
 
 typedef struct {
@@ -130,6 +131,7 @@ int64_t fo_pattern(int nnode, int64_t nel, int npe, const int32_t* conn, int ndo
 
 /* Mazars equivalent strain of DamageMaterial (test hook): eq, d eq / d strain [STRAIN_COUNTS], principal values [3] */
 int fo_mazars(const fo_config* cfg, int rank, const double* strain, double* eq, double* deriv, double* princ);
+int fo_vonmises(const fo_config* cfg, const double* strain6, double* eq, double* deriv);
 
 /* Element-serial assembly (LinearElasticityModel.cpp:297-430, PhaseFractureModel.cpp:502-751,
  * PhaseFractureExtModel.cpp:488-774, PhaseFractureExtItModel.cpp:518-797).

@@ -23,7 +23,7 @@ HISTORY_MODELS = (PHASE_FRACTURE, MICRO_PHASE_FRACTURE, MICRO_EXT, MICRO_EXTIT, 
 HOOKE, AMOR, BOURDIN, MIEHE, DAMAGE = range(5)
 (SOFT_PERFECT, SOFT_LINEAR1, SOFT_LINEAR2, SOFT_EXPONENTIAL1, SOFT_EXPONENTIAL2, SOFT_POWER, SOFT_HYPERBOLIC,
  SOFT_EXPONENTIAL2REG, SOFT_EXPOENERGY, SOFT_POLYNOMIAL, SOFT_MULTILINEAR) = range(11)
-EQV_ENERGY, EQV_MAZARS = 0, 1
+EQV_ENERGY, EQV_MAZARS, EQV_VONMISES = 0, 1, 2
 PLANE_STRAIN, PLANE_STRESS = 0, 1
 AT1, AT2, CZM_LINEAR, CZM_EXPONENTIAL, CZM_CORNELISSEN, CZM_HYPERBOLIC = range(6)
 PATTERN_FULL, PATTERN_WRITTEN = 0, 1
@@ -37,7 +37,7 @@ class Config(C.Structure):
                 ("keep_off_diags", C.c_int),
                 ("softening", C.c_int), ("kappa_i", C.c_double), ("kappa_c", C.c_double), ("soft_alpha", C.c_double),
                 ("soft_beta", C.c_double), ("length_scale", C.c_double), ("eqv_strain", C.c_int),
-                ("soft_b", C.c_double), ("soft_s", C.c_double), ("kappa_p", C.c_double)]
+                ("soft_b", C.c_double), ("soft_s", C.c_double), ("kappa_p", C.c_double), ("eta", C.c_double)]
 
 
 class ShapeInfo(C.Structure):
@@ -80,6 +80,7 @@ def lib():
         L.fo_stress_table.argtypes = [C.POINTER(Config), C.c_int64, ip32, dp, C.c_int, dp, dp]
         L.fo_last_error.restype = C.c_char_p
         L.fo_mazars.argtypes = [C.POINTER(Config), C.c_int, dp, dp, dp, dp]
+        L.fo_vonmises.argtypes = [C.POINTER(Config), dp, dp, dp]
         L.fo_arc_func.argtypes = [C.POINTER(Config), C.c_int, dp, C.c_int64, ip32, dp, dp, dp, dp]
         L.fo_eval_masters.argtypes = [dp, C.POINTER(Cons)]; L.fo_eval_masters.restype = None
         L.fo_eval_slaves.argtypes = [dp, C.POINTER(Cons)]; L.fo_eval_slaves.restype = None
@@ -139,10 +140,10 @@ def ndof_per_node(model, rank):
 
 def make_config(shape, model, material, state=PLANE_STRAIN, young=210e3, poisson=0.3, frac_type=AT2,
                 gc=2.7, l0=0.015, sigma_t=0.0, beta=6500.0, keep_off_diags=0, softening=0, kappa_i=0.0, kappa_c=0.0,
-                soft_alpha=0.0, soft_beta=0.0, length_scale=0.0, eqv_strain=0, soft_b=0.0, soft_s=0.0, kappa_p=0.0):
+                soft_alpha=0.0, soft_beta=0.0, length_scale=0.0, eqv_strain=0, soft_b=0.0, soft_s=0.0, kappa_p=0.0, eta=0.0):
     return Config(shape, model, material, state, young, poisson, frac_type, gc, l0, sigma_t, beta,
                   int(keep_off_diags), softening, kappa_i, kappa_c, soft_alpha, soft_beta, length_scale, eqv_strain,
-                  soft_b, soft_s, kappa_p)
+                  soft_b, soft_s, kappa_p, eta)
 
 
 def psi0(cfg):
@@ -163,6 +164,14 @@ def material_update(cfg, rank, strain, gphi=1.0):
                                 _p(stiff, C.c_double), C.byref(psi), _p(sp, C.c_double)):
         raise ValueError(lib().fo_last_error().decode())
     return stress, stiff, psi.value, sp
+
+
+def vonmises(cfg, strain6):
+    """(eq, d eq / d strain) of the restated von Mises equivalent strain for a 6-component strain vector."""
+    strain6 = np.ascontiguousarray(strain6, dtype=np.float64)
+    eq = C.c_double(); d = np.zeros(6)
+    lib().fo_vonmises(C.byref(cfg), _p(strain6, C.c_double), C.byref(eq), _p(d, C.c_double))
+    return eq.value, d
 
 
 def mazars(cfg, rank, strain):

@@ -279,9 +279,9 @@ def damage_law(soft, Ki, Kc, al, be, K):
     return (0.0 if K < Kp else (0.999 if K > Kc else (K - Kp) / (Kc - Kp))), (1 / (Kc - Kp) if K < Kc else 0.0)
 
 
-def element_gd(x, N, dN, w, u, eqv, kap0, load0, D0, law, c, want_K=True, mazars=None):
+def element_gd(x, N, dN, w, u, eqv, kap0, load0, D0, law, c, want_K=True, mazars=None, vonmises=None):
     """returns K1, K2, K3, K4, f1, f2, kappa, loading.  law = (soft, Ki, Kc, alpha, beta); mazars = (nu, plane_stress)
-    for eqvStrain = Mazars, None for Energy."""
+    for eqvStrain = Mazars, vonmises = (eta, nu) for vonMises (rank 3), both None for Energy."""
     npe, rank = x.shape
     nd = rank * npe
     K1 = np.zeros((nd, nd)); K2 = np.zeros((nd, npe)); K3 = np.zeros((npe, nd)); K4 = np.zeros((npe, npe))
@@ -304,13 +304,13 @@ def element_gd(x, N, dN, w, u, eqv, kap0, load0, D0, law, c, want_K=True, mazars
         om, dom = damage_law(*law, kap[ip])
         D = (1 - om) * D0
         K1 += wip * B.T @ D @ B
-        deq = D0 @ eps if mazars is None else mazars_deriv(eps, *mazars)
+        deq = vonmises_deriv(eps, *vonmises) if vonmises else D0 @ eps if mazars is None else mazars_deriv(eps, *mazars)
         K3 -= wip * np.outer(Nip, deq @ B)
         if ld[ip]:
             K2 -= wip * dom * B.T @ D0 @ np.outer(eps, Nip)
         K4 += wip * (np.outer(Nip, Nip) + c * g @ g.T)
         f1 += wip * B.T @ (D @ eps)
-        f2 -= wip * (0.5 * eps @ D0 @ eps if mazars is None else mazars_eq(eps)) * Nip
+        f2 -= wip * (vonmises_eq(eps, *vonmises) if vonmises else 0.5 * eps @ D0 @ eps if mazars is None else mazars_eq(eps)) * Nip
     f2 += K4 @ eqv
     return K1, K2, K3, K4, f1, f2, kap, ld
 
@@ -384,3 +384,29 @@ def mazars_deriv(strain, nu, plane_stress):
     ret[1] = (p0 * b + p1 * a + p2 * poiD) / den
     ret[3] = (p0 * c - p1 * c) / den
     return ret
+
+
+# ---- von Mises equivalent strain (DamageMaterial.cpp:609-617, :667-684; VonMisesStrain.cpp): written from the tensor
+# definition -- J2 = 1/2 dev : dev -- not from the reference's component formulas; its gradient is taken with respect
+# to the tensor components for the shear entries too (twice the derivative with respect to gamma), as the reference does ----
+def _vm_parts(strain, eta, nu):
+    e = np.array([[strain[0], strain[3] / 2, strain[5] / 2], [strain[3] / 2, strain[1], strain[4] / 2],
+                  [strain[5] / 2, strain[4] / 2, strain[2]]])
+    I1 = np.trace(e); dev = e - I1 / 3 * np.eye(3)
+    J2 = 0.5 * np.tensordot(dev, dev)
+    a = (eta - 1) / (1 - 2 * nu); b = 0.5 / eta; c = 12 * eta / (1 + nu) ** 2
+    return I1, J2, dev, a, b, c
+
+
+def vonmises_eq(strain, eta, nu):
+    I1, J2, _, a, b, c = _vm_parts(strain, eta, nu)
+    return b * (a * I1 + np.sqrt(a * a * I1 * I1 + c * J2))
+
+
+def vonmises_deriv(strain, eta, nu):
+    I1, J2, dev, a, b, c = _vm_parts(strain, eta, nu)
+    d = np.sqrt(a * a * I1 * I1 + c * J2)
+    d = 1.0 if d == 0.0 else d
+    dI1 = a * b + b / d * a * a * I1; dJ2 = b / d * c * 0.5
+    gJ2 = np.array([dev[0, 0], dev[1, 1], dev[2, 2], 2 * dev[0, 1], 2 * dev[1, 2], 2 * dev[0, 2]])   # dJ2/de_ij, shear doubled
+    return dI1 * np.array([1.0, 1, 1, 0, 0, 0]) + dJ2 * gJ2

@@ -13,6 +13,7 @@ from tests import np_ref
 from tests.test_oracle_kat import GRID, csr_dense
 
 E, NU = 210.0, 0.3
+ETA = 10.0                             # vonMises only
 LAWS = {po.SOFT_PERFECT: dict(kappa_i=1.0e-3),
         po.SOFT_LINEAR1: dict(kappa_i=1.0e-3, kappa_c=4.0e-3),
         po.SOFT_LINEAR2: dict(kappa_i=1.0e-3, kappa_c=4.0e-3),
@@ -40,7 +41,7 @@ def law_tuple(soft):
 
 def gd_config(shape, soft, state2d=po.PLANE_STRAIN, c=0.02, eqv=po.EQV_ENERGY):
     return po.make_config(shape, po.GRADIENT_DAMAGE, po.DAMAGE, state=state2d, young=E, poisson=NU, softening=soft,
-                          length_scale=c, eqv_strain=eqv, **LAWS[soft])
+                          length_scale=c, eqv_strain=eqv, eta=ETA, **LAWS[soft])
 
 
 def gd_state(coords, rank, seed=3):
@@ -151,7 +152,8 @@ def test_uniaxial_element_closed_form():
     (po.QUAD8_G3, po.SOFT_EXPONENTIAL1, po.EQV_MAZARS, po.PLANE_STRESS),
     (po.QUAD4_G2, po.SOFT_POWER, po.EQV_ENERGY, po.PLANE_STRAIN), (po.TRI3_G1, po.SOFT_HYPERBOLIC, po.EQV_MAZARS, po.PLANE_STRESS),
     (po.QUAD4_G2, po.SOFT_EXPONENTIAL2REG, po.EQV_ENERGY, po.PLANE_STRAIN), (po.HEX8_G2, po.SOFT_EXPOENERGY, po.EQV_ENERGY, po.PLANE_STRAIN),
-    (po.TRI6_G3, po.SOFT_POLYNOMIAL, po.EQV_ENERGY, po.PLANE_STRESS), (po.QUAD4_G2, po.SOFT_MULTILINEAR, po.EQV_MAZARS, po.PLANE_STRAIN)])
+    (po.TRI6_G3, po.SOFT_POLYNOMIAL, po.EQV_ENERGY, po.PLANE_STRESS), (po.QUAD4_G2, po.SOFT_MULTILINEAR, po.EQV_MAZARS, po.PLANE_STRAIN),
+    (po.HEX8_G2, po.SOFT_EXPONENTIAL1, po.EQV_VONMISES, po.PLANE_STRAIN), (po.HEX20_G2, po.SOFT_LINEAR1, po.EQV_VONMISES, po.PLANE_STRAIN)])
 def test_oracle_vs_numpy_restatement(shape, soft, eqv, state2d):
     rank, npe, nip, _ = po.shape_info(shape)
     coords, conn = GRID[shape]()
@@ -165,6 +167,7 @@ def test_oracle_vs_numpy_restatement(shape, soft, eqv, state2d):
     N, dN, w = po.shape_tables(shape)
     D0 = np_ref.hooke(rank, state2d, E, NU)
     maz = (NU, state2d == po.PLANE_STRESS) if eqv == po.EQV_MAZARS else None
+    vm = (ETA, NU) if eqv == po.EQV_VONMISES else None
     law = law_tuple(soft)
     ndof = nn * nd
     K = np.zeros((ndof, ndof)); f = np.zeros(ndof); Hn = np.zeros_like(H0)
@@ -173,7 +176,8 @@ def test_oracle_vs_numpy_restatement(shape, soft, eqv, state2d):
         ud = np.array([[n * nd + i for i in range(rank)] for n in c]).ravel(); pd = c * nd + rank
         h = H0[e * nip:(e + 1) * nip]
         K1, K2, K3, K4, f1, f2, kap, ld = np_ref.element_gd(coords[c], N, dN, w, S[c, :rank].ravel(), S[c, rank],
-                                                            np.abs(h), (h < 0).astype(int), D0, law, 0.02, mazars=maz)
+                                                            np.abs(h), (h < 0).astype(int), D0, law, 0.02, mazars=maz,
+                                                            vonmises=vm)
         K[np.ix_(ud, ud)] += K1; K[np.ix_(pd, pd)] += K4
         K[np.ix_(ud, pd)] += K2; K[np.ix_(pd, ud)] += K3
         f[ud] += f1; f[pd] += f2; Hn[e * nip:(e + 1) * nip] = np.where(ld == 1, -kap, kap)
@@ -249,6 +253,27 @@ def test_mazars_principal_values_and_derivative():
     assert po.mazars(cfg, 2, np.zeros(4))[0] == 0.0 and np.all(po.mazars(cfg, 3, np.zeros(6))[1] == 0.0)   # NaN roots count as "not positive"
 
 
+def test_vonmises_equivalent_strain_known_answers():
+    """Uniaxial tension e: I1 = e (1 - 2 nu), J2 = e^2 (1 + nu)^2 / 3, so eq = e exactly for every eta (the measure is
+    built that way); uniaxial compression gives eq = e / eta; the C restatement against the numpy one on random strains."""
+    cfg = gd_config(po.HEX8_G2, po.SOFT_PERFECT, eqv=po.EQV_VONMISES)
+    e = 2.0e-3
+    uni = np.array([e, -NU * e, -NU * e, 0, 0, 0])
+    eq, d = po.vonmises(cfg, uni)
+    assert abs(eq - e) < 1e-15 and abs(po.vonmises(cfg, -uni)[0] - e / ETA) < 1e-15
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        s6 = rng.uniform(-3e-3, 3e-3, 6)
+        eq, d = po.vonmises(cfg, s6)
+        assert abs(eq - np_ref.vonmises_eq(s6, ETA, NU)) < 1e-13 * abs(eq)
+        assert np.allclose(d, np_ref.vonmises_deriv(s6, ETA, NU), rtol=1e-12, atol=1e-15)
+        h = 1e-7                                                             # normal components: a true derivative; the
+        for i in range(6):                                                   # shear ones are twice d eq / d gamma (as in the reference)
+            dp = s6.copy(); dm = s6.copy(); dp[i] += h; dm[i] -= h
+            fd = (np_ref.vonmises_eq(dp, ETA, NU) - np_ref.vonmises_eq(dm, ETA, NU)) / (2 * h)
+            assert abs((d[i] if i < 3 else 0.5 * d[i]) - fd) < 1e-6 * max(1.0, abs(fd))
+
+
 def test_refusals():
     coords, conn = meshgen.grid_quad4(1, 1)
     rp, ci = po.pattern(4, conn, 3, 2)
@@ -280,7 +305,9 @@ GPU_MESH = {po.TRI3_G1: lambda: meshgen.grid_tri3(9, 7), po.QUAD4_G2: lambda: me
     (po.QUAD4_G2, po.SOFT_EXPONENTIAL2REG, po.PLANE_STRAIN, 0), (po.QUAD4_G2, po.SOFT_EXPOENERGY, po.PLANE_STRESS, 1),
     (po.QUAD8_G3, po.SOFT_EXPOENERGY, po.PLANE_STRAIN, 0), (po.TRI6_G3, po.SOFT_POLYNOMIAL, po.PLANE_STRAIN, 0),
     (po.HEX8_G2, po.SOFT_POLYNOMIAL, po.PLANE_STRAIN, 1), (po.QUAD4_G2, po.SOFT_MULTILINEAR, po.PLANE_STRAIN, 1),
-    (po.HEX20_G2, po.SOFT_MULTILINEAR, po.PLANE_STRAIN, 0)])
+    (po.HEX20_G2, po.SOFT_MULTILINEAR, po.PLANE_STRAIN, 0),
+    (po.HEX8_G2, po.SOFT_EXPONENTIAL1, po.PLANE_STRAIN, 2), (po.HEX8_G2, po.SOFT_HYPERBOLIC, po.PLANE_STRAIN, 2),   # vonMises
+    (po.HEX20_G2, po.SOFT_LINEAR1, po.PLANE_STRAIN, 2)])
 def test_gpu_gradient_damage_parity(shape, soft, state2d, eqv):
     """K + f pass, commit, K + f pass on the unchanged state (the f == 0 branch), then a force-only pass, each against
     the oracle carrying its own history the same way."""
@@ -295,7 +322,7 @@ def test_gpu_gradient_damage_parity(shape, soft, state2d, eqv):
     st = gd_state(coords, rank)
     H0 = gd_history(conn.shape[0] * nip)
     asm = capi.Assembler(shape, capi.GRADIENT_DAMAGE, capi.DAMAGE, coords, conn, state=state2d, young=E, poisson=NU,
-                         softening=soft, length_scale=0.02, eqv_strain=eqv, **LAWS[soft])
+                         softening=soft, length_scale=0.02, eqv_strain=eqv, eta=ETA, **LAWS[soft])
     rp, ci = asm.pattern()
     rpo, cio = po.pattern(coords.shape[0], conn, rank + 1, rank, po.PATTERN_FULL, po.keep_code(cfg))
     assert np.array_equal(rp, rpo) and np.array_equal(ci, cio)
@@ -339,8 +366,15 @@ def test_gpu_gradient_damage_refusals():
     with pytest.raises(capi.FaError):
         capi.Assembler(capi.QUAD4_G2, capi.GRADIENT_DAMAGE, capi.DAMAGE, coords, conn, young=E, poisson=NU,
                        softening=capi.SOFT_LINEAR1, kappa_i=2e-3, kappa_c=1e-3)
-    with pytest.raises(capi.FaError):                                         # vonMises (2) and anything else
+    with pytest.raises(capi.FaError):                                         # vonMises (2) on a 2-D shape
         capi.Assembler(capi.QUAD4_G2, capi.GRADIENT_DAMAGE, capi.DAMAGE, coords, conn, young=E, poisson=NU,
+                       softening=capi.SOFT_PERFECT, kappa_i=1e-3, eqv_strain=2, eta=10.0)
+    with pytest.raises(capi.FaError):
+        capi.Assembler(capi.QUAD4_G2, capi.GRADIENT_DAMAGE, capi.DAMAGE, coords, conn, young=E, poisson=NU,
+                       softening=capi.SOFT_PERFECT, kappa_i=1e-3, eqv_strain=3)
+    c3, n3 = meshgen.grid_hex8(2, 2, 2)
+    with pytest.raises(capi.FaError):                                         # vonMises without eta
+        capi.Assembler(capi.HEX8_G2, capi.GRADIENT_DAMAGE, capi.DAMAGE, c3, n3, young=E, poisson=NU,
                        softening=capi.SOFT_PERFECT, kappa_i=1e-3, eqv_strain=2)
 
 
