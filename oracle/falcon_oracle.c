@@ -19,7 +19,8 @@
  *   src/materials/MiehePhaseMaterial.cpp:80-149,200-258,342-406
  *   src/util/ShapeUtils.cpp:73-145, TensorUtils.cpp, MathUtils.cpp:23-41, Constants.cpp:9
  *   src/fem/solidmech/MicroPhaseFracture{,Ext,ExtIt}Model.cpp (getMatrix_), PhaseFractureModel.cpp:844-1063 (getArcFunc_)
- *   src/fem/solidmech/GradientDamageModel.cpp:368-588, src/materials/DamageMaterial.cpp:356-440,602-706,886-1032,1044-1289
+ *   src/fem/solidmech/GradientDamageModel.cpp:368-588, src/materials/DamageMaterial.cpp:356-440,602-706,886-1032,1044-1633
+ *   src/materials/VonMisesStrain.cpp:34-116
  *   src/util/Invariants.cpp:35-224, MathUtils.cpp:112-182 (solveCubicEqn), Constants.cpp:13-18
  */
 #include "falcon_oracle.h"
