@@ -34,8 +34,8 @@ def algorithmic_bytes(nnz_written, ndof, nnode, rank, npe, nel, nip, phase_field
 
 
 def workload(name, n, capi, material="amor", keep=False, dims=None):
-    mat = {"amor": capi.AMOR_PHASE, "miehe": capi.MIEHE_PHASE, "bourdin": capi.BOURDIN_PHASE}[material]
-    mname = {"amor": "AmorPhase", "miehe": "MiehePhase", "bourdin": "BourdinPhase"}[material]
+    mat = {"amor": capi.AMOR_PHASE, "miehe": capi.MIEHE_PHASE, "bourdin": capi.BOURDIN_PHASE, "amor-split": capi.AMOR_PHASE}[material]
+    mname = {"amor": "AmorPhase", "miehe": "MiehePhase", "bourdin": "BourdinPhase", "amor-split": "AmorPhase"}[material]
     if name == "cfg2":
         n = n or 1000
         return dict(desc=f"cfg2: {n}x{n} Q4 linear-elastic plate (Hooke, plane strain)", shape=capi.QUAD4_G2,
@@ -49,9 +49,10 @@ def workload(name, n, capi, material="amor", keep=False, dims=None):
                     kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=keep))
     if name == "cfg3micro":      # the micromorphic variant on the cfg3 mesh (Miehe / Bourdin, penalty 250)
         n = n or 4000
-        m2 = capi.BOURDIN_PHASE if material == "bourdin" else capi.MIEHE_PHASE
+        m2 = {"bourdin": capi.BOURDIN_PHASE, "miehe": capi.MIEHE_PHASE, "amor": capi.MIEHE_PHASE, "amor-split": capi.AMOR_PHASE}[material]
+        mn2 = {capi.BOURDIN_PHASE: "BourdinPhase", capi.MIEHE_PHASE: "MiehePhase", capi.AMOR_PHASE: "AmorPhase"}[m2]
         return dict(desc=f"cfg3micro: {n}x{n} Q4, MicroPhaseFracture (u-phi, local damage by Newton), AT2, "
-                         f"{'BourdinPhase' if material == 'bourdin' else 'MiehePhase'}, keepOffDiags={'true' if keep else 'false'}",
+                         f"{mn2}, keepOffDiags={'true' if keep else 'false'}",
                     shape=capi.QUAD4_G2, model=capi.MICRO_PHASE_FRACTURE, material=m2, dims=(n, n), h=1.0 / n,
                     written_per_pair=9 if keep else 5,
                     kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=keep, beta=250.0))
@@ -144,7 +145,7 @@ def main():
     ap.add_argument("--dims", default="", help="3-D workloads: elements per direction as nx,ny,nz (overrides --n)")
     ap.add_argument("--mode", default="overwrite", choices=["overwrite", "accumulate"])
     ap.add_argument("--pattern", default="full", choices=["full", "written"])
-    ap.add_argument("--material", default="amor", choices=["amor", "miehe", "bourdin"])
+    ap.add_argument("--material", default="amor", choices=["amor", "miehe", "bourdin", "amor-split"])
     ap.add_argument("--keep-off-diags", action="store_true")
     ap.add_argument("--force-only", action="store_true", help="GET_INT_VECTOR pass instead of GET_MATRIX0")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: one full-size block per GPU | the one mesh divided")

@@ -373,6 +373,8 @@ struct fa_ctx {
           *d_prec = nullptr, *d_prun = nullptr;
   double* d_hist[2] = { nullptr, nullptr };   // [0] preHist_, [1] newHist_
   double* d_strain = nullptr; double* d_err_part = nullptr;
+  unsigned long long* d_first_comp = nullptr;   // MicroPhaseFracture* + AmorPhase: first compression point of the call
+  bool d_first_comp_needed = false;
   double* d_out_tmp = nullptr;         // fa_output_data: strain and stress tables + weights before the column filter
   double* d_arc_part = nullptr;        // fa_arc_func: per-workgroup partial sums of FE_DISSIPATION
   int32_t* d_row_ptr32 = nullptr;      // fa_pattern_device32: the offsets as 32-bit integers, made on first request
@@ -391,7 +393,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
   if (!c) return;
   DeviceGuard guard(c->prob.device);
   void* ptrs[] = { c->d_conn, c->d_coords, c->d_row_ptr, c->d_col_idx, c->d_node_dofs, c->d_n2e_ptr, c->d_n2e_ent,
-                   c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part, c->d_row_ptr32, c->d_arc_part, c->d_out_tmp,
+                   c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part, c->d_first_comp, c->d_row_ptr32, c->d_arc_part, c->d_out_tmp,
                    c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err,
                    c->d_pn_ptr, c->d_pe_ptr, c->d_pr_ptr, c->d_pnode, c->d_poff, c->d_prec, c->d_prun,
                    c->d_tinfo, c->d_tnodes, c->d_telems, c->d_tconn, c->d_tpairs, c->d_tents,
@@ -444,10 +446,12 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   }
   c->fam = !pf ? fa::FAM_LE : (p->material == FA_MIEHE_PHASE ? fa::FAM_PF_MIEHE : fa::FAM_PF_ISO);
   if (p->model >= FA_MICRO_PHASE_FRACTURE && p->model <= FA_MICRO_PHASE_FRACTURE_EXTIT) {
-    // AmorPhase's split update leaves stiffN untouched in tension (AmorPhaseMaterial.cpp:239-268), so the reference's
-    // result depends on what an earlier Gauss point of its serial loop left there: not reproducible in parallel
-    if (p->material == FA_AMOR_PHASE) return fail(FA_ERR_UNSUPPORTED, "MicroPhaseFracture* with AmorPhase depends on the serial Gauss-point order of the reference (stale stiffN); not available on the device");
+    // AmorPhase's split update leaves stiffN untouched in tension (AmorPhaseMaterial.cpp:239-268): a point in tension finds
+    // what the last compression point of the serial loop left there.  That is K PVol from the first compression point of
+    // the call on -- first_comp_kernel finds it before the assembly kernel runs -- and the array's initial contents before
+    // (Jem does not initialise it; zero is assumed here and in the checker).
     c->fam = fa::FAM_PF_MIEHE;                          // general-tangent family (rank-one term of elemMat1)
+    c->d_first_comp_needed = (p->material == FA_AMOR_PHASE);
   }
   if (sh.rank == 2 && p->state != FA_PLANE_STRAIN && p->state != FA_PLANE_STRESS)
     return fail(FA_ERR_ARG, "unexpected rank/state");     // HookeMaterial.cpp:262-265
@@ -917,7 +921,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   fa::TileSet tsK, tsF;
   {
     const bool shape_ok = p->shape == FA_QUAD4_G2 || p->shape == FA_TRI3_G1;
-    const bool wanted = (dbg.emat >= 0 ? dbg.emat != 0 : false) && !gd;   // (no GradientDamage instantiations of the opt-in kernel)
+    const bool wanted = (dbg.emat >= 0 ? dbg.emat != 0 : false) && !gd && !c->d_first_comp_needed;   // (no GradientDamage / Micro + AmorPhase instantiations of the opt-in kernel)
     if (shape_ok && wanted && P.canon && nel > 0) {
       const bool keepK = P.keep2 || P.keep3;
       const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE && p->model != FA_GRADIENT_DAMAGE;
@@ -1057,6 +1061,8 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   }
   c->max_parts = std::max(std::max(std::max(std::max(std::max(c->nwg, c->ntile2), c->ngrid_generic), c->npatch), c->ngrid_coop), c->ntile3);
   c->max_parts = std::max(c->max_parts, std::max(std::max(c->ematK.ntile, c->ematF.ntile), c->fvec.ntile));
+  if (p->model >= FA_MICRO_PHASE_FRACTURE && p->model <= FA_MICRO_PHASE_FRACTURE_EXTIT && p->material == FA_AMOR_PHASE)
+    HIP_TRY(hipMalloc((void**)&c->d_first_comp, sizeof(unsigned long long)));
   if (p->model == FA_PHASE_FRACTURE_EXTIT || p->model == FA_MICRO_PHASE_FRACTURE_EXTIT)
     HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(c->max_parts, 1)));
   HIP_TRY(hipDeviceSynchronize());
@@ -1251,6 +1257,14 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   if (!dbgbuf) { HIP_TRY(hipMalloc(&dbgbuf, dbgbytes)); HIP_TRY(hipMemset(dbgbuf, 0, dbgbytes)); }
   P.dbg = dbgbuf;
 #endif
+  P.first_comp = nullptr;
+  if (c->d_first_comp) {                                // buffer of the context (fa_create): nothing is allocated here
+    HIP_TRY(hipMemsetAsync(c->d_first_comp, 0xff, sizeof(unsigned long long), st));
+    const int rc0 = (c->rank == 2) ? fa::launch_first_comp_2d(P, c->npe, c->nip, c->d_first_comp, (void*)st)
+                                   : fa::launch_first_comp_3d(P, c->npe, c->nip, c->d_first_comp, (void*)st);
+    if (rc0 != 0) return fail(FA_ERR_HIP, "first_comp_kernel launch failed: %s", hipGetErrorString((hipError_t)rc0));
+    P.first_comp = c->d_first_comp;
+  }
   int rc = c->launch(P, c->fam, want_K, keep, path, grid, (void*)st);
 #ifdef FA_TRACE
   if (++ncall == 6 && getenv("FA_TRACE_FILE")) {

@@ -322,6 +322,9 @@ static int launch_coop_one(const Params& P, int grid, hipStream_t st) {
   if constexpr (FAM == FAM_PF_ISO) {                   // GradientDamage: its own instantiation (SpecGD)
     if (P.model == 7) { hipLaunchKernelGGL((assemble_coop<SH, FAM, WANT_K, KEEP, SpecGD<SpecRuntime>>), dim3(grid), dim3(256), 0, st, P); return (int)hipGetLastError(); }
   }
+  if constexpr (FAM == FAM_PF_MIEHE) {                 // MicroPhaseFracture* + AmorPhase (SpecMA)
+    if (is_micro_amor(P)) { hipLaunchKernelGGL((assemble_coop<SH, FAM, WANT_K, KEEP, SpecMA<SpecRuntime>>), dim3(grid), dim3(256), 0, st, P); return (int)hipGetLastError(); }
+  }
   hipLaunchKernelGGL((assemble_coop<SH, FAM, WANT_K, KEEP, SpecRuntime>), dim3(grid), dim3(256), 0, st, P);
   return (int)hipGetLastError();
 }

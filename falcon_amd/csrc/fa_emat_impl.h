@@ -1026,7 +1026,10 @@ static int launch_fvec_shape(const Params& P, int fam, int grid, void* stream) {
     if (P.model == 7) return launch_fvec_one<SH, FAM_PF_ISO, SpecGD<SpecCanon>>(P, grid, st);
     return launch_fvec_one<SH, FAM_PF_ISO, SpecCanon>(P, grid, st);
   }
-  if (fam == FAM_PF_MIEHE) return launch_fvec_one<SH, FAM_PF_MIEHE, SpecCanon>(P, grid, st);
+  if (fam == FAM_PF_MIEHE) {
+    if (is_micro_amor(P)) return launch_fvec_one<SH, FAM_PF_MIEHE, SpecMA<SpecCanon>>(P, grid, st);
+    return launch_fvec_one<SH, FAM_PF_MIEHE, SpecCanon>(P, grid, st);
+  }
   return -1000;
 }
 

@@ -175,6 +175,9 @@ struct Params {
   int32_t k2sig, pstress;    // K2 from the stress record (sig / (1 - omega) = D0 eps) because sp holds d eq / d eps; plane stress
   double kI, kC, sA, sB, poiD;   // poiD = nu / (nu - 1) (DamageMaterial.cpp:971)
   double vmA, vmB, vmC;          // VonMisesStrain::init (VonMisesStrain.cpp:34-43)
+  // MicroPhaseFracture* with AmorPhase: serial index (e * nip + ip) of the first Gauss point with trace(strain) <= 0 in this
+  // call, found by first_comp_kernel before the assembly kernel runs; nullptr for every other model / material
+  const unsigned long long* first_comp;
 };
 
 // launchers, one translation unit per shape (fa_kernels_<shape>.hip)
@@ -199,6 +202,10 @@ int launch_fvec_hex8_g2 (const Params&, int fam, int grid, void* stream);
 // getStress_ table kernels, one per space dimension (fa_kernels_quad4.hip / fa_kernels_hex8.hip)
 int launch_stress_table_2d(const Params&, int npe, int nip, int plane_stress, double* table, double* weights, void* stream);
 int launch_stress_table_3d(const Params&, int npe, int nip, int plane_stress, double* table, double* weights, void* stream);
+
+// MicroPhaseFracture* + AmorPhase: first compression point of the call (same translation units)
+int launch_first_comp_2d(const Params&, int npe, int nip, unsigned long long* first, void* stream);
+int launch_first_comp_3d(const Params&, int npe, int nip, unsigned long long* first, void* stream);
 
 // getArcFunc_ kernels (same translation units)
 int launch_arc_func_2d(const Params&, int npe, int nip, const double* state0, double* jac10, double* part, void* stream);

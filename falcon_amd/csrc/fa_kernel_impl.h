@@ -47,6 +47,7 @@ struct Shape {
 // (uniform branches); SpecFixed folds model / degradation exponent / material into the code and promises the
 // canonical dof numbering (the row kernels' precondition), which removes every uniform branch from the Gauss-point loop.
 struct SpecRuntime {
+  static constexpr bool ma = false;                    // MicroPhaseFracture* + AmorPhase: SpecMA
   static constexpr bool gd = false;                    // GradientDamage has kernels of its own (SpecGD): its constitutive
                                                        // branch (exp, acos, cos) costs every runtime-model kernel registers
   static __device__ __forceinline__ int model(const Params& P) { return P.model; }
@@ -59,7 +60,7 @@ struct SpecCanon : SpecRuntime {                       // runtime model, canonic
 };
 template <int MODEL, int PTYPE, int MAT>
 struct SpecFixed {
-  static constexpr bool gd = false;
+  static constexpr bool gd = false, ma = false;
   static __device__ __forceinline__ constexpr int model(const Params&) { return MODEL; }
   static __device__ __forceinline__ constexpr int ptype(const Params&) { return PTYPE; }
   static __device__ __forceinline__ constexpr int material(const Params&) { return MAT; }
@@ -72,6 +73,14 @@ struct SpecGD : BASE {
   static constexpr bool gd = true;
   static __device__ __forceinline__ constexpr int model(const Params&) { return 7; }
 };
+
+// MicroPhaseFracture / Ext / ExtIt with AmorPhase (general-tangent family): the only instantiations with its split update
+template <class BASE>
+struct SpecMA : BASE {
+  static constexpr bool ma = true;
+  static __device__ __forceinline__ constexpr int material(const Params&) { return 1; }
+};
+static inline bool is_micro_amor(const Params& P) { return P.model >= 4 && P.model <= 6 && P.material == 1; }
 
 template <int I, int N>
 struct SFor {
@@ -570,6 +579,37 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
         };
         if (SP::material(P) == 3) {
           miehe_update_f<RANK, S>(P, eps, gfun, r.D, r.sig, sp, Psi);
+        } else if constexpr (SP::ma) {
+          // AmorPhase, split update (AmorPhaseMaterial.cpp:239-271), in instantiations of its own (SpecMA: inside the
+          // runtime-model kernels it cost the Quad8 tile kernel its second workgroup per CU): stiffP = 2G PDev (+ K PVol in
+          // tension); stiffN = K PVol is written at compression points only (:256-263) and the model's array is never reset
+          // (MicroPhaseFractureModel.cpp:535), so a point in tension finds K PVol once the serial loop has passed a
+          // compression point (first_comp_kernel) and the array's initial contents -- zero assumed, as in the checker -- before.
+          const double tr = (RANK == 3) ? (eps[0] + eps[1] + eps[RANK - 1]) : (eps[0] + eps[1] + 0.0);
+          double dd = 2.0 * P.G * (2.0 / 3.0), od = 2.0 * P.G * (-1.0 / 3.0);
+          const double sh = 2.0 * P.G * 0.5;
+          if (tr > 0.0) { dd += P.Kb; od += P.Kb; }
+          double psi2 = 0.0;
+#pragma unroll
+          for (int i = 0; i < S; i++) {
+            double acc = 0.0;
+            if (i < RANK) {
+#pragma unroll
+              for (int j = 0; j < RANK; j++) acc += ((i == j) ? dd : od) * eps[j];
+            } else acc = sh * eps[i];
+            sp[i] = acc; psi2 += acc * eps[i];
+          }
+          Psi = 0.5 * psi2;
+          const double g = gfun(Psi, sp);
+          const double kn = (tr <= 0.0 || (unsigned long long)ipoint > *P.first_comp) ? P.Kb : 0.0;
+          const double sn = kn * tr;
+#pragma unroll
+          for (int i = 0; i < S; i++) {
+            r.sig[i] = g * sp[i] + ((i < RANK) ? sn : 0.0);
+#pragma unroll
+            for (int j = 0; j < S; j++)
+              r.D[i][j] = (i < RANK && j < RANK) ? g * ((i == j) ? dd : od) + kn : ((i == j) ? g * sh : 0.0);
+          }
         } else {                                        // BourdinPhase: stiffP = D, stiffN = 0 (BourdinPhaseMaterial.cpp:148-166)
           double psi2 = 0.0;
 #pragma unroll
@@ -1732,6 +1772,7 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
         else go(SpecCanon{});
       } else {
         if (P.model == 1 && P.ptype == 0) go(SpecFixed<1, 0, 3>{});
+        else if (is_micro_amor(P)) go(SpecMA<SpecCanon>{});
         else go(SpecCanon{});
       }
     }
@@ -1750,11 +1791,15 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
       else go(SpecCanon{});
     } else {
       if (P.model == 1 && P.ptype == 0) go(SpecFixed<1, 0, 3>{});
+      else if (is_micro_amor(P)) go(SpecMA<SpecCanon>{});
       else go(SpecCanon{});
     }
   } else {
     if constexpr (FAM == FAM_PF_ISO) {
       if (P.model == 7) { hipLaunchKernelGGL((assemble_generic<SH, FAM, WANT_K, KEEP, SpecGD<SpecRuntime>>), dim3(grid), dim3(SH::BLOCK), 0, st, P); return (int)hipGetLastError(); }
+    }
+    if constexpr (FAM == FAM_PF_MIEHE) {
+      if (is_micro_amor(P)) { hipLaunchKernelGGL((assemble_generic<SH, FAM, WANT_K, KEEP, SpecMA<SpecRuntime>>), dim3(grid), dim3(SH::BLOCK), 0, st, P); return (int)hipGetLastError(); }
     }
     hipLaunchKernelGGL((assemble_generic<SH, FAM, WANT_K, KEEP, SpecRuntime>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
   }

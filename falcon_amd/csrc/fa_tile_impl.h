@@ -1050,6 +1050,76 @@ __global__ __launch_bounds__(128) void arc_func_kernel(const Params P, int npe, 
   if (threadIdx.x == 0) part[blockIdx.x] = sfv[0];
 }
 
+// MicroPhaseFracture* with AmorPhase: the reference's split material update writes stiffN only at Gauss points with
+// trace(strain) <= 0 (AmorPhaseMaterial.cpp:256-263) into an array that lives outside the model's element loop
+// (MicroPhaseFractureModel.cpp:535), so every later point of the serial loop in tension finds K PVol there.  One lane per
+// (element, Gauss point): the smallest serial index e * nip + ip of a compression point, by a 64-bit atomic minimum.
+template <int RANK>
+__global__ __launch_bounds__(256) void first_comp_kernel(const Params P, int npe, int nip, unsigned long long* __restrict__ first) {
+  constexpr int ND = RANK + 1;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P.nel * nip) return;
+  // workgroups start roughly in order: once an earlier point has been found the later ones have nothing to add
+  if ((unsigned long long)t >= *(volatile unsigned long long*)first) return;
+  const int64_t e = t / nip; const int ip = (int)(t - e * nip);
+  auto dof = [&](int64_t node, int k) -> int64_t { return P.node_dofs ? P.node_dofs[node * ND + k] : node * ND + k; };
+  const double* dn = P.tab + (size_t)nip * npe + (size_t)ip * npe * RANK;
+  const int32_t* cn = P.conn + e * npe;
+  double J[RANK][RANK], inv[RANK][RANK];
+#pragma unroll
+  for (int i = 0; i < RANK; i++)
+#pragma unroll
+    for (int k = 0; k < RANK; k++) J[i][k] = 0.0;
+  for (int b = 0; b < npe; b++) {
+    const double* xb = P.coords + (int64_t)cn[b] * RANK;
+#pragma unroll
+    for (int i = 0; i < RANK; i++)
+#pragma unroll
+      for (int k = 0; k < RANK; k++) J[i][k] += xb[i] * dn[b * RANK + k];
+  }
+  if constexpr (RANK == 2) {
+    const double rd = 1.0 / (J[0][0] * J[1][1] - J[0][1] * J[1][0]);
+    inv[0][0] = J[1][1] * rd;  inv[0][1] = -J[0][1] * rd;
+    inv[1][0] = -J[1][0] * rd; inv[1][1] = J[0][0] * rd;
+  } else {
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double rd = 1.0 / (J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02);
+    inv[0][0] = c00 * rd;
+    inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
+    inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * rd;
+    inv[1][0] = c01 * rd;
+    inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * rd;
+    inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rd;
+    inv[2][0] = c02 * rd;
+    inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
+    inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
+  }
+  double en[RANK];                                     // the normal strains, summed over the nodes as ip_point_core does
+#pragma unroll
+  for (int i = 0; i < RANK; i++) en[i] = 0.0;
+  for (int b = 0; b < npe; b++) {
+#pragma unroll
+    for (int i = 0; i < RANK; i++) {
+      double g = 0.0;
+#pragma unroll
+      for (int k = 0; k < RANK; k++) g += dn[b * RANK + k] * inv[k][i];
+      en[i] += g * P.state[dof(cn[b], i)];
+    }
+  }
+  const double tr = (RANK == 3) ? (en[0] + en[1] + en[RANK - 1]) : (en[0] + en[1] + 0.0);
+  if (tr <= 0.0 && (unsigned long long)t < *(volatile unsigned long long*)first) atomicMin(first, (unsigned long long)t);
+}
+
+template <int RANK>
+static int launch_first_comp_rank(const Params& P, int npe, int nip, unsigned long long* first, void* stream) {
+  const int64_t n = P.nel * nip;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(first_comp_kernel<RANK>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, npe, nip, first);
+  return (int)hipGetLastError();
+}
+
 template <int RANK>
 static int launch_arc_func_rank(const Params& P, int npe, int nip, const double* state0, double* jac10, double* part, void* stream) {
   hipLaunchKernelGGL(arc_func_kernel<RANK>, dim3((unsigned)((P.nnode + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
@@ -1079,6 +1149,12 @@ static int launch_tiles_shape(const Params& P, int fam, bool want_K, bool keep, 
                 : launch_tiles_one<SH, FAM_PF_ISO, true, false, SpecCanon>(P, grid, st);
   }
   if (fam == FAM_PF_MIEHE) {
+    if (is_micro_amor(P)) {                             // MicroPhaseFracture* + AmorPhase (SpecMA)
+      using SPM = SpecMA<SpecCanon>;
+      if (!want_K) return launch_tiles_one<SH, FAM_PF_MIEHE, false, false, SPM>(P, grid, st);
+      return keep ? launch_tiles_one<SH, FAM_PF_MIEHE, true, true, SPM>(P, grid, st)
+                  : launch_tiles_one<SH, FAM_PF_MIEHE, true, false, SPM>(P, grid, st);
+    }
     if (!want_K) return launch_tiles_one<SH, FAM_PF_MIEHE, false, false, SpecCanon>(P, grid, st);
     return keep ? launch_tiles_one<SH, FAM_PF_MIEHE, true, true, SpecCanon>(P, grid, st)
                 : launch_tiles_one<SH, FAM_PF_MIEHE, true, false, SpecCanon>(P, grid, st);

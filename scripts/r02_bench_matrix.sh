@@ -17,6 +17,7 @@ t --workload tri3 --n 2000 --force-only
 t --workload tri3g3 --n 2000
 t --workload cfg3micro
 t --workload cfg3micro --material bourdin
+t --workload cfg3micro --material amor-split
 t --workload cfg4 --n 128
 t --workload cfg4 --n 128 --keep-off-diags
 t --workload cfg4 --n 128 --force-only

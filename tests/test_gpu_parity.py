@@ -384,11 +384,13 @@ ALL_SHAPES = [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2] + HIGH_ORDER
 
 
 def run_micro(shape, material, keep, *, flags=capi.OVERWRITE, want_K=True, commit=False, frac=capi.AT2, sigma_t=0.0,
-              young=210.0, gc=2.7e-3, l0=0.2, tol=TOL, model=capi.MICRO_PHASE_FRACTURE, beta=250.0):
+              young=210.0, gc=2.7e-3, l0=0.2, tol=TOL, model=capi.MICRO_PHASE_FRACTURE, beta=250.0, state_mod=None):
     import torch
     coords, conn, st, kw, cfg = make_case(shape, model, material, keep, frac=frac, sigma_t=sigma_t,
                                           young=young, gc=gc, l0=l0)
     kw["beta"] = beta
+    if state_mod is not None:
+        st = state_mod(coords, conn, st.copy())
     cfg = po.make_config(shape, model, material, **kw)
     asm = capi.Assembler(shape, model, material, coords, conn, **kw)
     rp, ci = asm.pattern()
@@ -444,12 +446,39 @@ def test_micro_fracture_laws(frac):
     run_micro(capi.QUAD4_G2, capi.MIEHE_PHASE, keep=1, frac=frac, sigma_t=3.0, young=3e4, gc=0.12, l0=0.25, tol=1e-11)
 
 
-def test_micro_amor_is_refused():
-    """AmorPhase's split update reads a stiffN left by an earlier Gauss point of the reference's serial loop; the
-    library refuses the combination instead of returning something order-dependent."""
-    coords, conn = meshgen.grid_quad4(3, 3)
-    with pytest.raises(capi.FaError, match="serial Gauss-point order"):
-        capi.Assembler(capi.QUAD4_G2, capi.MICRO_PHASE_FRACTURE, capi.AMOR_PHASE, coords, conn)
+def _expand_leading_elements(frac, amount):
+    """state_mod: a uniform expansion added to the displacements of the nodes of the first `frac` of the elements, so that
+    the serial loop meets its first compression point late (or never, frac = 1)."""
+    def mod(coords, conn, st):
+        rank = coords.shape[1]; nd = rank + 1
+        nodes = np.unique(conn[:max(1, int(frac * conn.shape[0]))])
+        S = st.reshape(-1, nd)
+        if frac >= 1.0:
+            S[:, :rank] = 0.0
+        S[nodes, :rank] += amount * coords[nodes]
+        return S.ravel()
+    return mod
+
+
+@pytest.mark.parametrize("shape", ALL_SHAPES)
+def test_micro_amor(shape):
+    """AmorPhase's split update (AmorPhaseMaterial.cpp:239-271) writes stiffN = K PVol at compression points only, into an
+    array the model never resets (MicroPhaseFractureModel.cpp:535): a point in tension sees K PVol once the serial loop has
+    passed a compression point, the array's initial contents (zero assumed by the checker and the library) before.  The
+    library finds the first compression point of the call with a pre-pass; three states: mixed from the start, compression
+    only after the first 60 % of the elements, none at all."""
+    run_micro(shape, capi.AMOR_PHASE, keep=1, commit=True)
+    run_micro(shape, capi.AMOR_PHASE, keep=0, want_K=False)
+    run_micro(shape, capi.AMOR_PHASE, keep=0, state_mod=_expand_leading_elements(0.6, 0.02))
+    run_micro(shape, capi.AMOR_PHASE, keep=1, state_mod=_expand_leading_elements(1.0, 0.01))
+
+
+@pytest.mark.parametrize("model", [capi.MICRO_PHASE_FRACTURE_EXT, capi.MICRO_PHASE_FRACTURE_EXTIT])
+def test_micro_ext_amor(model):
+    for shape in (capi.QUAD4_G2, capi.HEX8_G2, capi.TRI6_G3):
+        run_micro(shape, capi.AMOR_PHASE, keep=0, model=model, commit=True, state_mod=_expand_leading_elements(0.3, 0.02))
+    run_micro(capi.QUAD4_G2, capi.AMOR_PHASE, keep=0, model=model, want_K=False, flags=capi.OVERWRITE | capi.DETERMINISTIC)
+    run_micro(capi.TRI3_G1, capi.AMOR_PHASE, keep=0, model=model, flags=capi.OVERWRITE | capi.FORCE_GENERIC)
 
 
 # ---- MicroPhaseFractureExt / MicroPhaseFractureExtIt (SURVEY.md 8f, N1) ----
