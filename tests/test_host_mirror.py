@@ -120,7 +120,8 @@ def test_phase_fracture_models_through_take_action():
 
 
 @pytest.mark.gpu
-def test_micro_phase_fracture_through_take_action():
+@pytest.mark.parametrize("matname", ["MiehePhase", "AmorPhase"])
+def test_micro_phase_fracture_through_take_action(matname):
     """"MicroPhaseFracture" (first of the micromorphic variants): GET_MATRIX0, COMMIT (local damage swap),
     GET_INT_VECTOR; penalty defaults to 250 (MicroPhaseFractureModel.cpp:269)."""
     from falcon_amd import meshgen
@@ -132,14 +133,14 @@ def test_micro_phase_fracture_through_take_action():
     mesh += "</Elements>\n<ElementGroup name=\"all\">\n{" + ",".join(str(e + 1) for e in range(len(conn))) + "}\n</ElementGroup>\n"
     pro = '''model = "Matrix" { matrix.type = "FEM"; model = "Multi" { models = ["bulk"];
       bulk = "MicroPhaseFracture" { elements = "all"; shape = { type = "Quad4"; intScheme = "Gauss2*Gauss2"; };
-        material = { type = "MiehePhase"; rank = 2; state = "PLANE_STRAIN"; young = 210.0; poisson = 0.3; };
-        fractureType = "at2"; griffithEnergy = 2.7e-3; lengthScale = 0.2; keepOffDiags = true; }; }; };'''
+        material = { type = "%s"; rank = 2; state = "PLANE_STRAIN"; young = 210.0; poisson = 0.3; };
+        fractureType = "at2"; griffithEnergy = 2.7e-3; lengthScale = 0.2; keepOffDiags = true; }; }; };''' % matname
     st = meshgen.smooth_state(coords, 3, amp=5e-3, noise=1e-4, l0=0.3)
     case = hostapi.Case(pro, mesh)
     assert case.model_type == "MicroPhaseFracture"
     rp, ci = case.pattern()
-    cfg = po.make_config(po.QUAD4_G2, po.MICRO_PHASE_FRACTURE, po.MIEHE, young=210.0, poisson=0.3, gc=2.7e-3, l0=0.2,
-                         keep_off_diags=1, beta=250.0)
+    cfg = po.make_config(po.QUAD4_G2, po.MICRO_PHASE_FRACTURE, po.MIEHE if matname == "MiehePhase" else po.AMOR, young=210.0,
+                         poisson=0.3, gc=2.7e-3, l0=0.2, keep_off_diags=1, beta=250.0)
     ok, K, f = case.take_action("GET_MATRIX0", state=st)
     r1 = po.assemble(cfg, coords, conn, rp, ci, st)
     assert ok and np.abs(K - r1["K"]).max() < 1e-12 * np.abs(K).max() and np.abs(f - r1["f"]).max() < 1e-12 * np.abs(f).max()
