@@ -447,6 +447,29 @@ class SolidAssemblyModel : public Model {
     createContext_(mb.get());
   }
 
+  // GradientDamageModel::setConstraints_ (GradientDamageModel.cpp:682-846): the nonlocal strain is interpolated one order
+  // below the displacements, so the eqv dof of every mid-side node is tied to the mean of the edge's two corner dofs
+  // (coefficients 0.5); a dof that is already a slave is left alone; linear shapes return at once; shapes other than
+  // Line3 / Triangle6 / Quad8 are an IllegalInputException
+  void setConstraints_(Constraints& cons) {
+    if (shape_ == FA_TRI3_G1 || shape_ == FA_TRI3_G3 || shape_ == FA_QUAD4_G2) return;          // :705-724
+    // :789-799 -- hexahedra, 8 nodes included, are in neither of the reference's lists (Jive's geometry name is not
+    // visible here, so the message carries the node count only)
+    if (shape_ == FA_HEX8_G2) throw Error(myName_, "unsupported shape geometry: hexahedron, 8 nodes");
+    if (shape_ == FA_HEX20_G2 || shape_ == FA_HEX20_G3) throw Error(myName_, "unsupported shape geometry: hexahedron, 20 nodes");
+    const int nedge = (shape_ == FA_TRI6_G3) ? 3 : 4, npe = 2 * nedge;                          // Jive order: corner, mid, corner, ...
+    const int eqvType = types_.back();
+    const std::vector<double> coeffs = { 0.5, 0.5 };
+    for (int32_t ie : ielems_) {
+      const std::vector<int32_t>& inodes = mesh_->elems[ie];
+      for (int j = 0; j < nedge; j++) {                                                         // cdofs columns (:747-788)
+        const int64_t idof = dofs_->getDofIndex(inodes[2 * j + 1], eqvType);
+        if (cons.isSlaveDof(idof)) continue;
+        cons.addConstraint(idof, { dofs_->getDofIndex(inodes[2 * j], eqvType), dofs_->getDofIndex(inodes[(2 * j + 2) % npe], eqvType) }, coeffs);
+      }
+    }
+  }
+
   // DamageMaterial::configure (src/materials/DamageMaterial.cpp:157-315): same property names, ranges and messages
   void configureDamage_(const Properties& props) {
     if (!props.find(kappaI_, "kappaI")) {
@@ -509,8 +532,10 @@ class SolidAssemblyModel : public Model {
     }
     if (action == Actions::GET_MATRIX2) throw Error(myName_, "GET_MATRIX2 is not served by the GPU assembly path");
     if (kind_ == FA_GRADIENT_DAMAGE && action == "INIT") {                 // GradientDamageModel.cpp:321-330, setConstraints_ :682-724
-      if (shape_ == FA_TRI3_G1 || shape_ == FA_TRI3_G3 || shape_ == FA_QUAD4_G2) return true;   // linear shapes: nothing to constrain
-      throw Error(myName_, "the mid-node constraints of the nonlocal strain on higher-order shapes (setConstraints_) are not mirrored");
+      std::shared_ptr<Constraints> cons;                                 // Constraints::get ( dofs_, globdat )
+      if (!globdat.find(cons, Globdat::CONSTRAINTS)) { cons = std::make_shared<Constraints>(); globdat.set(Globdat::CONSTRAINTS, cons); }
+      setConstraints_(*cons);
+      return true;
     }
     if (action == Actions::COMMIT) {
       if (kind_ == FA_PHASE_FRACTURE || kind_ >= FA_MICRO_PHASE_FRACTURE) check_(fa_commit(ctx_));   // newHist_.swap(preHist_)
@@ -738,6 +763,24 @@ extern "C" const char* fh_model_type(fh_case* c) { return c->modelType.c_str(); 
 extern "C" void fh_pattern(fh_case* c, int64_t* rp, int32_t* ci) {
   std::copy(c->matrix->rowOffsets.begin(), c->matrix->rowOffsets.end(), rp);
   std::copy(c->matrix->colIndices.begin(), c->matrix->colIndices.end(), ci);
+}
+// constraints held in globdat (GradientDamage INIT): count, then slave / two-masters-and-coefficients per constraint
+extern "C" int64_t fh_constraint_count(fh_case* c) {
+  std::shared_ptr<Constraints> cons;
+  return c->globdat.find(cons, Globdat::CONSTRAINTS) ? (int64_t)cons->all().size() : 0;
+}
+extern "C" int64_t fh_constraints(fh_case* c, int64_t* slaves, int64_t* master_ptr, int64_t* masters, double* coefs, int64_t cap) {
+  std::shared_ptr<Constraints> cons;
+  if (!c->globdat.find(cons, Globdat::CONSTRAINTS)) return 0;
+  int64_t k = 0, m = 0;
+  master_ptr[0] = 0;
+  for (const auto& q : cons->all()) {
+    if (m + (int64_t)q.masters.size() > cap) return -1;
+    slaves[k] = q.slave;
+    for (size_t i = 0; i < q.masters.size(); i++) { masters[m] = q.masters[i]; coefs[m] = q.coefs[i]; m++; }
+    master_ptr[++k] = m;
+  }
+  return k;
 }
 extern "C" int64_t fh_dof_index(fh_case* c, int64_t node_id, const char* type) {
   std::shared_ptr<XDofSpace> d; c->globdat.get(d, Globdat::DOFS);

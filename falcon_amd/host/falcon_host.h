@@ -79,6 +79,20 @@ class XDofSpace {
   int64_t count_ = 0;
 };
 
+// ---- jive::util::Constraints stand-in: linear constraints u[slave] = rvalue + sum coef * u[master], in insertion order ----
+class Constraints {
+ public:
+  struct Con { int64_t slave; double rvalue; std::vector<int64_t> masters; std::vector<double> coefs; };
+  bool isSlaveDof(int64_t idof) const { return slaveIndex_.count(idof) != 0; }
+  void addConstraint(int64_t idof, const std::vector<int64_t>& jdofs, const std::vector<double>& coeffs) {
+    if (isSlaveDof(idof)) { cons_[slaveIndex_[idof]] = Con{idof, 0.0, jdofs, coeffs}; return; }
+    slaveIndex_[idof] = cons_.size(); cons_.push_back(Con{idof, 0.0, jdofs, coeffs});
+  }
+  const std::vector<Con>& all() const { return cons_; }
+ private:
+  std::vector<Con> cons_; std::map<int64_t, size_t> slaveIndex_;
+};
+
 // ---- jive::algebra::MatrixBuilder stand-in, matrix.type = "FEM": pattern fixed by mesh x dof space ----------
 class MatrixBuilder {
  public:
@@ -108,6 +122,7 @@ struct ActionParams {
 struct Globdat {
   static constexpr const char* MESH = "mesh";             // shared_ptr<Mesh>
   static constexpr const char* DOFS = "dofs";             // shared_ptr<XDofSpace>
+  static constexpr const char* CONSTRAINTS = "constraints";   // shared_ptr<Constraints> (Constraints::get (dofs, globdat))
   static constexpr const char* STATE = "state";           // Vector (StateVector::get)
   static constexpr const char* STATE_OLD = "state0";      // StateVector::getOld
   static constexpr const char* STATE_OLD_OLD = "state00"; // StateVector::getOldOld

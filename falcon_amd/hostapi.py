@@ -30,6 +30,8 @@ def lib():
         L.fh_model_type.argtypes = [vp]; L.fh_model_type.restype = C.c_char_p
         L.fh_pattern.argtypes = [vp, vp, vp]; L.fh_pattern.restype = None
         L.fh_dof_index.argtypes = [vp, C.c_int64, C.c_char_p]; L.fh_dof_index.restype = C.c_int64
+        L.fh_constraint_count.argtypes = [vp]; L.fh_constraint_count.restype = C.c_int64
+        L.fh_constraints.argtypes = [vp, vp, vp, vp, vp, C.c_int64]; L.fh_constraints.restype = C.c_int64
         L.fh_take_action.argtypes = [vp, C.c_char_p, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp]
         _lib = L
     return _lib
@@ -58,6 +60,16 @@ class Case:
         rp = np.empty(self.ndof + 1, dtype=np.int64); ci = np.empty(self.nnz, dtype=np.int32)
         lib().fh_pattern(self.h, _p(rp), _p(ci))
         return rp, ci
+
+    def constraints(self):
+        """(slaves, master_ptr, masters, coefs) of the Constraints the models have added (GradientDamage's INIT), in the
+        layout fa_cons_create takes."""
+        n = lib().fh_constraint_count(self.h)
+        slaves = np.zeros(n, dtype=np.int64); mp = np.zeros(n + 1, dtype=np.int64)
+        masters = np.zeros(2 * n + 1, dtype=np.int64); coefs = np.zeros(2 * n + 1)
+        if n and lib().fh_constraints(self.h, _p(slaves), _p(mp), _p(masters), _p(coefs), 2 * n) != n:
+            raise HostError("constraints with more than two masters")
+        return slaves, mp, masters[:mp[-1]], coefs[:mp[-1]]
 
     def dof(self, node_id, dof_type):
         return lib().fh_dof_index(self.h, node_id, dof_type.encode())

@@ -317,3 +317,43 @@ def test_sm03_with_the_other_softening_laws(name, props, kw):
     r = po.assemble(cfg, coords, conn, rp, ci, st)
     assert ok and (r["hist_new"] < 0).sum() > 20
     assert np.abs(K - r["K"]).max() < 1e-12 * np.abs(r["K"]).max() and np.abs(f - r["f"]).max() < 1e-12 * np.abs(r["f"]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape_name,scheme,gen", [("Triangle6", "Gauss3", "grid_tri6"), ("Quad8", "Gauss3*Gauss3", "grid_quad8"),
+                                                   ("Hex8", "Gauss2*Gauss2*Gauss2", "grid_hex8")])
+def test_gradient_damage_init_constrains_the_mid_nodes(shape_name, scheme, gen):
+    """GradientDamageModel::setConstraints_ (GradientDamageModel.cpp:682-846) under the INIT action: the eqv dof of every
+    mid-side node = 0.5 * (its edge's two corner dofs), first element to reach an edge wins; hexahedra are an error in the
+    reference (:789-799), Hex8 included."""
+    from falcon_amd import meshgen
+    rank = 3 if shape_name == "Hex8" else 2
+    coords, conn = getattr(meshgen, gen)(*((3, 2, 2) if rank == 3 else (4, 3)))
+    mesh = "<Nodes>\n" + "".join(f"{i + 1} " + " ".join(f"{v:.17g}" for v in x) + ";\n" for i, x in enumerate(coords)) + "</Nodes>\n"
+    mesh += "<Elements>\n" + "".join(f"{e + 1} " + " ".join(str(n + 1) for n in c) + ";\n" for e, c in enumerate(conn))
+    mesh += "</Elements>\n<ElementGroup name=\"all\">\n{" + ",".join(str(e + 1) for e in range(len(conn))) + "}\n</ElementGroup>\n"
+    pro = '''model = "Matrix" { matrix.type = "FEM"; model = "Multi" { models = ["bulk"];
+      bulk = "GradientDamage" { elements = "all"; shape = { type = "%s"; intScheme = "%s"; };
+        material = { type = "Damage"; rank = %d; state = "PLANE_STRAIN"; young = 210.0; poisson = 0.3;
+                     softening = "exponential2"; eqvStrain = "Energy"; kappaI = 1.e-3; kappaC = 6.e-3; lengthScale = 0.02; }; }; }; };''' % (shape_name, scheme, rank)
+    case = hostapi.Case(pro, mesh)
+    if rank == 3:
+        with pytest.raises(hostapi.HostError, match="unsupported shape geometry"):
+            case.take_action("INIT")
+        return
+    assert case.take_action("INIT")[0] is True
+    slaves, mp, masters, coefs = case.constraints()
+    nd = rank + 1
+    expect = {}
+    for c in conn:                                                    # reference order: elements, then edges
+        npe = len(c)
+        for j in range(npe // 2):
+            s = int(c[2 * j + 1]) * nd + rank
+            if s not in expect:
+                expect[s] = (int(c[2 * j]) * nd + rank, int(c[(2 * j + 2) % npe]) * nd + rank)
+    assert list(slaves) == list(expect.keys())                        # insertion order
+    assert np.array_equal(mp, 2 * np.arange(len(slaves) + 1)) and np.all(coefs == 0.5)
+    assert [tuple(masters[2 * k:2 * k + 2]) for k in range(len(slaves))] == list(expect.values())
+    mids = set(int(n) for n in np.unique(conn[:, 1::2]))
+    assert set(s // nd for s in slaves) == mids and len(slaves) == len(mids)   # every mid-side node exactly once
+    assert case.take_action("INIT")[0] is True and len(case.constraints()[0]) == len(slaves)   # idempotent: already slaves
