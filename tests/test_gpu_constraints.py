@@ -204,3 +204,44 @@ def test_pattern_with_32_bit_offsets():
     assert np.array_equal(rp32.astype(np.int64), rp) and np.array_equal(ci32, ci)
     assert capi.lib().fa_device(asm.h) == 0
     asm.close()
+
+
+@pytest.mark.parametrize("shape,gen", [(capi.QUAD8_G3, "grid_quad8"), (capi.TRI6_G3, "grid_tri6")])
+def test_gradient_damage_mid_node_constraints_need_no_fill_in(shape, gen):
+    """The constraints GradientDamageModel::setConstraints_ adds under INIT (GradientDamageModel.cpp:682-846: eqv dof of a
+    mid-side node = mean of its edge's corner dofs) eliminated on the device from a GradientDamage matrix in its canonical
+    pattern: every fold destination lies inside an element that holds the edge, so no extra entries are needed."""
+    import torch
+    coords, conn = getattr(meshgen, gen)(6, 5)
+    coords = meshgen.distort(coords, conn, 0.05, 3)
+    nd = 3
+    slave, mdof = [], []
+    for c in conn:
+        for j in range(len(c) // 2):
+            s = int(c[2 * j + 1]) * nd + 2
+            if s not in slave:
+                slave.append(s); mdof += [int(c[2 * j]) * nd + 2, int(c[(2 * j + 2) % len(c)]) * nd + 2]
+    slave = np.array(slave); mdof = np.array(mdof); mptr = 2 * np.arange(slave.size + 1); mcoef = np.full(mdof.size, 0.5)
+    asm = capi.Assembler(shape, capi.GRADIENT_DAMAGE, capi.DAMAGE, coords, conn, young=210.0, poisson=0.3,
+                         softening=capi.SOFT_EXPONENTIAL2, kappa_i=1e-3, kappa_c=6e-3, length_scale=0.02)
+    dev = torch.device("cuda", 0)
+    st = meshgen.smooth_state(coords, nd, seed=2, amp=5e-3, noise=1e-4, l0=0.3).reshape(-1, nd)
+    st[:, 2] = 3e-3 + 2e-3 * np.sin(3 * coords[:, 0])
+    K = torch.zeros(asm.nnz, dtype=torch.float64, device=dev); f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+    asm.assemble(torch.from_numpy(st.ravel().copy()).to(dev), K, f, flags=capi.OVERWRITE)
+    torch.cuda.synchronize()
+    rp, ci = asm.pattern()
+    cons = asm.constraints(slave, None, mptr, mdof, mcoef)                # canonical pattern: accepted as it is
+    ref = po.Constraints(slave, None, mptr, mdof, mcoef)
+    Kh = K.cpu().numpy().copy(); rh = -f.cpu().numpy().copy()
+    rhs = (-f).clone()
+    cons.eliminate(K, rhs)
+    torch.cuda.synchronize()
+    ref.eliminate(rp, ci, Kh, rh)
+    assert np.abs(K.cpu().numpy() - Kh).max() <= 1e-12 * np.abs(Kh).max()
+    assert np.abs(rhs.cpu().numpy() - rh).max() <= 1e-12 * np.abs(rh).max()
+    u = torch.from_numpy(st.ravel().copy()).to(dev)
+    cons.eval_slaves(u)                                                   # the nonlocal strain becomes edge-wise linear
+    uh = u.cpu().numpy()
+    assert np.abs(uh[slave] - 0.5 * (uh[mdof[0::2]] + uh[mdof[1::2]])).max() == 0.0
+    cons.close(); asm.close()
