@@ -82,6 +82,19 @@ def workload(name, n, capi, material="amor", keep=False, dims=None):
                          f"keepOffDiags={'true' if keep else 'false'}", shape=shape, model=capi.PHASE_FRACTURE,
                     material=mat, dims=(n, n), h=1.0 / n, written_per_pair=9 if keep else 5, gen=gen,
                     kw=dict(young=210e3, poisson=0.3, gc=2.7, l0=0.015, frac_type=capi.AT2, keep_off_diags=keep))
+    if name in ("gd", "gd3"):    # GradientDamage + Damage (the material of the reference's tests/sm03: exponential1
+        # softening; Mazars strain in 2-D on the cfg3 mesh, Energy in 3-D on the cfg4 mesh), all four blocks written
+        gdkw = dict(young=40e3, poisson=0.2, softening=capi.SOFT_EXPONENTIAL1, kappa_i=0.02, soft_alpha=0.92, soft_beta=30.0,
+                    length_scale=1.0e-6)
+        if name == "gd":
+            n = n or 4000
+            return dict(desc=f"gd: {n}x{n} Q4, GradientDamage (u-eqv), Damage: exponential1 softening, Mazars strain, plane stress",
+                        shape=capi.QUAD4_G2, model=capi.GRADIENT_DAMAGE, material=capi.DAMAGE, dims=(n, n), h=1.0 / n,
+                        written_per_pair=9, kw=dict(state=capi.PLANE_STRESS, eqv_strain=capi.EQV_MAZARS, **gdkw))
+        d3 = dims or ((n or 128),) * 3
+        return dict(desc=f"gd3: {d3[0]}x{d3[1]}x{d3[2]} hex8, GradientDamage (u-eqv), Damage: exponential1 softening, Energy strain",
+                    shape=capi.HEX8_G2, model=capi.GRADIENT_DAMAGE, material=capi.DAMAGE, dims=d3, h=1.0 / max(d3),
+                    written_per_pair=16, kw=dict(eqv_strain=capi.EQV_ENERGY, **gdkw))
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -101,7 +114,8 @@ def cpu_baseline(wl, capi, meshgen, target_elems):
     kw = dict(wl["kw"])
     cfg = po.make_config(wl["shape"], wl["model"], wl["material"], young=kw["young"], poisson=kw["poisson"],
                          gc=kw.get("gc", 2.7), l0=kw.get("l0", 0.015), frac_type=kw.get("frac_type", 1),
-                         keep_off_diags=int(kw.get("keep_off_diags", False)), beta=kw.get("beta", 6500.0))
+                         keep_off_diags=int(kw.get("keep_off_diags", False)), beta=kw.get("beta", 6500.0),
+                         **{k: kw[k] for k in ("state", "softening", "kappa_i", "soft_alpha", "soft_beta", "length_scale", "eqv_strain") if k in kw})
     nd = po.ndof_per_node(wl["model"], rank)
     rp, ci = po.pattern(coords.shape[0], conn, nd, rank)
     st = meshgen.smooth_state(coords, nd)

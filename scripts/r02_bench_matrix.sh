@@ -32,3 +32,7 @@ t --workload quad8g2 --n 1000
 t --workload quad8 --n 1000 --material miehe
 t --workload tri6 --n 1000
 t --workload tri6 --n 1000 --force-only
+t --workload gd
+t --workload gd --force-only
+t --workload gd3 --n 128
+t --workload gd3 --n 128 --force-only
