@@ -1773,6 +1773,7 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
       } else {
         if (P.model == 1 && P.ptype == 0) go(SpecFixed<1, 0, 3>{});
         else if (P.model == 4 && P.ptype == 0 && P.material == 3) go(SpecFixed<4, 0, 3>{});   // MicroPhaseFracture, AT1 / AT2, MiehePhase
+        // (BourdinPhase / AmorPhase folded in the same way measured slower: 4.99 against 4.77 ms, 5.18 against 5.08 ms)
         else if (is_micro_amor(P)) go(SpecMA<SpecCanon>{});
         else go(SpecCanon{});
       }
