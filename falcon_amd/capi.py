@@ -60,7 +60,7 @@ EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_
            "fa_assemble", "fa_assemble_noalloc", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
            "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum", "fa_strain_table", "fa_stress_table",
            "fa_pattern_device32", "fa_device", "fa_cons_create", "fa_cons_destroy", "fa_cons_set_rvalues", "fa_cons_eliminate",
-           "fa_cons_eval_masters", "fa_cons_eval_slaves", "fa_residual", "fa_arc_func", "fa_output_data"]
+           "fa_cons_eval_masters", "fa_cons_eval_slaves", "fa_residual", "fa_arc_func", "fa_output_data", "fa_micro_stale_hits"]
 
 _lib = None
 
@@ -119,6 +119,7 @@ def lib():
         L.fa_residual.argtypes = [vp] * 11
         L.fa_arc_func.argtypes = [vp] * 6
         L.fa_output_data.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
+        L.fa_micro_stale_hits.argtypes = [vp, C.POINTER(C.c_int64)]
         ip = C.POINTER(C.c_int32)
         L.fa_shape_info.argtypes = [C.c_int32, ip, ip, ip]
         L.fa_shape_tables.argtypes = [C.c_int32, vp, vp, vp]
@@ -316,6 +317,13 @@ class Assembler:
         v = np.ascontiguousarray(values, dtype=np.float64)
         assert v.size == self.nip_total
         _check(lib().fa_set_history(self.h, which, _np_ptr(v)))
+
+    def micro_stale_hits(self):
+        """Gauss points of the last assemble call in the `d > 1` branch of MicroPhaseFractureModel.cpp:772-776 (0 for every
+        other model): where the reference keeps a stale dphidStrain and the kernels use 0."""
+        n = C.c_int64(0)
+        _check(lib().fa_micro_stale_hits(self.h, C.byref(n)))
+        return n.value
 
     def get_strain_cache(self):
         out = np.empty((self.nip_total, self.strain_rows))

@@ -374,7 +374,10 @@ struct fa_ctx {
   double* d_hist[2] = { nullptr, nullptr };   // [0] preHist_, [1] newHist_
   double* d_strain = nullptr; double* d_err_part = nullptr;
   unsigned long long* d_first_comp = nullptr;   // MicroPhaseFracture* + AmorPhase: first compression point of the call
+  uint32_t* d_comp_mask = nullptr;              // ... and the compression bits of every element's Gauss points (same pre-pass)
   bool d_first_comp_needed = false;
+  unsigned long long* d_stale = nullptr;        // MicroPhaseFracture*: Gauss points of the last call in the `d > 1` branch
+  hipEvent_t done_ev = nullptr;                 // recorded at the end of every fa_assemble: what the host getters wait for
   double* d_out_tmp = nullptr;         // fa_output_data: strain and stress tables + weights before the column filter
   double* d_arc_part = nullptr;        // fa_arc_func: per-workgroup partial sums of FE_DISSIPATION
   int32_t* d_row_ptr32 = nullptr;      // fa_pattern_device32: the offsets as 32-bit integers, made on first request
@@ -384,7 +387,6 @@ struct fa_ctx {
   TileDev ematK, ematF;                // element-matrix kernel (Quad4 / Triangle3)
   TileDev fvec;                        // force-vector kernel (Quad4 / Triangle3)
   DebugOptions dbg;
-  hipStream_t last_stream = nullptr;   // stream of the last fa_assemble: the host getters / setters wait for it
 };
 
 extern "C" const char* fa_last_error(void) { return g_err.c_str(); }
@@ -393,7 +395,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
   if (!c) return;
   DeviceGuard guard(c->prob.device);
   void* ptrs[] = { c->d_conn, c->d_coords, c->d_row_ptr, c->d_col_idx, c->d_node_dofs, c->d_n2e_ptr, c->d_n2e_ent,
-                   c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part, c->d_first_comp, c->d_row_ptr32, c->d_arc_part, c->d_out_tmp,
+                   c->d_pos, c->d_wg_start, c->d_lrec, c->d_wginfo, c->d_lrec2, c->d_wginfo2, c->d_tab, c->d_hist[0], c->d_hist[1], c->d_strain, c->d_err_part, c->d_first_comp, c->d_comp_mask, c->d_stale, c->d_row_ptr32, c->d_arc_part, c->d_out_tmp,
                    c->s_state, c->s_state0, c->s_state00, c->s_K, c->s_f, c->s_err,
                    c->d_pn_ptr, c->d_pe_ptr, c->d_pr_ptr, c->d_pnode, c->d_poff, c->d_prec, c->d_prun,
                    c->d_tinfo, c->d_tnodes, c->d_telems, c->d_tconn, c->d_tpairs, c->d_tents,
@@ -401,6 +403,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
                    c->ematF.tinfo, c->ematF.tnodes, c->ematF.telems, c->ematF.tconn, c->ematF.tpairs, c->ematF.tents,
                    c->fvec.tinfo, c->fvec.tnodes, c->fvec.telems, c->fvec.tconn, c->fvec.tpairs, c->fvec.tents, c->fvec.eslot, c->fvec.nval };
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (c->done_ev) (void)hipEventDestroy(c->done_ev);
   delete c;
 }
 
@@ -873,7 +876,10 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       // against 10.9 ms)
       const int recw = fa::tile_rec_doubles(rank, c->fam, keepK, npe);
       const bool big = rank == 3 && (dbg.tile_big >= 0 ? dbg.tile_big != 0 : fa::tile_slot_doubles(sh.nip, recw) >= fa::kTileBigSlot);
-      P.tile_block = big ? fa::kTileBlockBig : fa::kTileBlock;
+      // FA_TILE_BIG=2: the big LDS budget with a 512-thread workgroup -- one workgroup per CU at two waves per SIMD, so the
+      // kernel may use 256 registers (1024 threads pin it at 128: the general-tangent kernels then spill 0.5 KB per lane)
+      const bool big512 = big && (dbg.tile_big >= 0 ? dbg.tile_big == 2 : false);
+      P.tile_block = (big && !big512) ? fa::kTileBlockBig : fa::kTileBlock;
       // one lane per unordered node pair across tiles (TileOpts::sym_all) unless the lanes are in row order
       fa::TileOpts topt;
       topt.sym_all = !row_order && (dbg.tile_sym >= 0 ? dbg.tile_sym != 0 : true);
@@ -1061,8 +1067,20 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   }
   c->max_parts = std::max(std::max(std::max(std::max(std::max(c->nwg, c->ntile2), c->ngrid_generic), c->npatch), c->ngrid_coop), c->ntile3);
   c->max_parts = std::max(c->max_parts, std::max(std::max(c->ematK.ntile, c->ematF.ntile), c->fvec.ntile));
-  if (p->model >= FA_MICRO_PHASE_FRACTURE && p->model <= FA_MICRO_PHASE_FRACTURE_EXTIT && p->material == FA_AMOR_PHASE)
+  if (p->model >= FA_MICRO_PHASE_FRACTURE && p->model <= FA_MICRO_PHASE_FRACTURE_EXTIT && p->material == FA_AMOR_PHASE) {
     HIP_TRY(hipMalloc((void**)&c->d_first_comp, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&c->d_comp_mask, sizeof(uint32_t) * std::max<int64_t>(nel, 1)));
+    if (dbg.verbose)
+      fprintf(stderr, "[falcon_assemble] MicroPhaseFracture* + AmorPhase: stiffN of a tension point is K PVol once the element loop has "
+              "passed a compression point and ZERO before (the reference reads an uninitialised array there); K and f_int therefore "
+              "depend on the element numbering and on the partition (include/falcon_assemble.h)\n");
+  }
+  if (p->model >= FA_MICRO_PHASE_FRACTURE && p->model <= FA_MICRO_PHASE_FRACTURE_EXTIT) {
+    HIP_TRY(hipMalloc((void**)&c->d_stale, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_stale, 0, sizeof(unsigned long long)));
+  }
+  // the host getters wait for this event instead of synchronising a caller's stream that may no longer exist
+  HIP_TRY(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
   if (p->model == FA_PHASE_FRACTURE_EXTIT || p->model == FA_MICRO_PHASE_FRACTURE_EXTIT)
     HIP_TRY(hipMalloc((void**)&c->d_err_part, sizeof(double) * std::max(c->max_parts, 1)));
   HIP_TRY(hipDeviceSynchronize());
@@ -1165,7 +1183,6 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   // served here because the kernel supports it.
   FA_ON_DEVICE(c->prob.device);
   hipStream_t st = (hipStream_t)a->stream;
-  c->last_stream = st;
   fa::Params P = c->P;
   P.state = a->state; P.state0 = a->state0; P.stateX = a->state00; P.dt = a->dt; P.dt0 = a->dt0;
   P.K = a->K_values; P.f = a->f_int;
@@ -1229,6 +1246,7 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
       HIP_TRY(hipMemsetAsync(a->f_int, 0, sizeof(double) * c->ndof, st));
     }
     if (want_err) HIP_TRY(hipMemsetAsync(a->err_ext, 0, sizeof(double), st));
+    HIP_TRY(hipEventRecord(c->done_ev, st));
     return FA_OK;
   }
   int grid;
@@ -1257,14 +1275,16 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   if (!dbgbuf) { HIP_TRY(hipMalloc(&dbgbuf, dbgbytes)); HIP_TRY(hipMemset(dbgbuf, 0, dbgbytes)); }
   P.dbg = dbgbuf;
 #endif
-  P.first_comp = nullptr;
+  P.first_comp = nullptr; P.comp_mask = nullptr;
   if (c->d_first_comp) {                                // buffer of the context (fa_create): nothing is allocated here
     HIP_TRY(hipMemsetAsync(c->d_first_comp, 0xff, sizeof(unsigned long long), st));
-    const int rc0 = (c->rank == 2) ? fa::launch_first_comp_2d(P, c->npe, c->nip, c->d_first_comp, (void*)st)
-                                   : fa::launch_first_comp_3d(P, c->npe, c->nip, c->d_first_comp, (void*)st);
+    const int rc0 = (c->rank == 2) ? fa::launch_first_comp_2d(P, c->npe, c->nip, c->d_first_comp, c->d_comp_mask, (void*)st)
+                                   : fa::launch_first_comp_3d(P, c->npe, c->nip, c->d_first_comp, c->d_comp_mask, (void*)st);
     if (rc0 != 0) return fail(FA_ERR_HIP, "first_comp_kernel launch failed: %s", hipGetErrorString((hipError_t)rc0));
-    P.first_comp = c->d_first_comp;
+    P.first_comp = c->d_first_comp; P.comp_mask = c->d_comp_mask;
   }
+  P.stale_hits = c->d_stale;
+  if (c->d_stale) HIP_TRY(hipMemsetAsync(c->d_stale, 0, sizeof(unsigned long long), st));
   int rc = c->launch(P, c->fam, want_K, keep, path, grid, (void*)st);
 #ifdef FA_TRACE
   if (++ncall == 6 && getenv("FA_TRACE_FILE")) {
@@ -1282,6 +1302,7 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
     hipLaunchKernelGGL(reduce_err_kernel, dim3(1), dim3(256), 0, st, err_part, nparts, a->err_ext);
     HIP_TRY(hipGetLastError());
   }
+  HIP_TRY(hipEventRecord(c->done_ev, st));
   return FA_OK;
 }
 
@@ -1339,7 +1360,7 @@ extern "C" fa_status fa_get_history(const fa_ctx* c, int32_t which, double* out)
   if (!c || !out || which < 0 || which > 1) return fail(FA_ERR_ARG, "bad argument");
   if (!c->d_hist[which]) return fail(FA_ERR_ARG, "this model keeps no history array");
   FA_ON_DEVICE(c->prob.device);
-  HIP_TRY(hipStreamSynchronize(c->last_stream));      // an assemble on a non-blocking stream may still be writing
+  HIP_TRY(hipEventSynchronize(c->done_ev));           // an assemble on a non-blocking stream may still be writing
   HIP_TRY(hipMemcpy(out, c->d_hist[which], sizeof(double) * c->nel * c->nip, hipMemcpyDeviceToHost));
   return FA_OK;
 }
@@ -1348,7 +1369,7 @@ extern "C" fa_status fa_set_history(fa_ctx* c, int32_t which, const double* in) 
   if (!c || !in || which < 0 || which > 1) return fail(FA_ERR_ARG, "bad argument");
   if (!c->d_hist[which]) return fail(FA_ERR_ARG, "this model keeps no history array");
   FA_ON_DEVICE(c->prob.device);
-  HIP_TRY(hipStreamSynchronize(c->last_stream));
+  HIP_TRY(hipEventSynchronize(c->done_ev));
   HIP_TRY(hipMemcpy(c->d_hist[which], in, sizeof(double) * c->nel * c->nip, hipMemcpyHostToDevice));
   return FA_OK;
 }
@@ -1449,7 +1470,6 @@ extern "C" fa_status fa_output_data(fa_ctx* c, int32_t ncols, const int32_t* col
 }
 
 // getArcFunc_ (PhaseFractureModel.cpp:844-1063)
-extern "C"// getArcFunc_ (PhaseFractureModel.cpp:844-1063)
 extern "C" fa_status fa_arc_func(fa_ctx* c, const double* state, const double* state0, double* jac10, double* fe_dissipation,
                                  void* stream) {
   if (!c || !state || !state0 || !jac10 || !fe_dissipation) return fail(FA_ERR_ARG, "null argument");
@@ -1501,7 +1521,21 @@ extern "C" fa_status fa_get_strain_cache(const fa_ctx* c, double* out) {
   if (!c || !out) return fail(FA_ERR_ARG, "bad argument");
   if (!c->d_strain) return fail(FA_ERR_ARG, "no call with FA_STORE_STRAIN has been made");
   FA_ON_DEVICE(c->prob.device);
-  HIP_TRY(hipStreamSynchronize(c->last_stream));
+  HIP_TRY(hipEventSynchronize(c->done_ev));
   HIP_TRY(hipMemcpy(out, c->d_strain, sizeof(double) * c->nel * c->nip * c->srows, hipMemcpyDeviceToHost));
+  return FA_OK;
+}
+
+// MicroPhaseFracture*: Gauss points of the last fa_assemble call that took the `d > 1` branch of
+// MicroPhaseFractureModel.cpp:772-776 (the reference keeps a stale dphidStrain there, the kernels use 0)
+extern "C" fa_status fa_micro_stale_hits(const fa_ctx* c, int64_t* out) {
+  if (!c || !out) return fail(FA_ERR_ARG, "bad argument");
+  *out = 0;
+  if (!c->d_stale) return FA_OK;                       // not a micromorphic model: the branch does not exist
+  FA_ON_DEVICE(c->prob.device);
+  HIP_TRY(hipEventSynchronize(c->done_ev));
+  unsigned long long v = 0;
+  HIP_TRY(hipMemcpy(&v, c->d_stale, sizeof v, hipMemcpyDeviceToHost));
+  *out = (int64_t)v;
   return FA_OK;
 }

@@ -178,6 +178,12 @@ struct Params {
   // MicroPhaseFracture* with AmorPhase: serial index (e * nip + ip) of the first Gauss point with trace(strain) <= 0 in this
   // call, found by first_comp_kernel before the assembly kernel runs; nullptr for every other model / material
   const unsigned long long* first_comp;
+  // ... and, per element, the bit mask of its Gauss points with trace(strain) <= 0 from the same pre-pass: the one
+  // classification every assembly kernel uses (their own strain arithmetic differs from path to path)
+  const uint32_t* comp_mask;
+  // MicroPhaseFracture*: counter of Gauss points that took the `d > 1` branch of MicroPhaseFractureModel.cpp:772-776, where
+  // the reference keeps a dphidStrain left over from an earlier point of its serial loop and the kernels use 0
+  unsigned long long* stale_hits;
 };
 
 // launchers, one translation unit per shape (fa_kernels_<shape>.hip)
@@ -204,8 +210,8 @@ int launch_stress_table_2d(const Params&, int npe, int nip, int plane_stress, do
 int launch_stress_table_3d(const Params&, int npe, int nip, int plane_stress, double* table, double* weights, void* stream);
 
 // MicroPhaseFracture* + AmorPhase: first compression point of the call (same translation units)
-int launch_first_comp_2d(const Params&, int npe, int nip, unsigned long long* first, void* stream);
-int launch_first_comp_3d(const Params&, int npe, int nip, unsigned long long* first, void* stream);
+int launch_first_comp_2d(const Params&, int npe, int nip, unsigned long long* first, uint32_t* mask, void* stream);
+int launch_first_comp_3d(const Params&, int npe, int nip, unsigned long long* first, uint32_t* mask, void* stream);
 
 // getArcFunc_ kernels (same translation units)
 int launch_arc_func_2d(const Params&, int npe, int nip, const double* state0, double* jac10, double* part, void* stream);

@@ -381,15 +381,16 @@ __device__ __forceinline__ void miehe_update(const Params& P, const double (&e)[
 // clipping branches.  Returns g(d) (no floor); out: d, g'(d) at the final d, dphidd and cdS with
 // dphidStrain = cdS * sigma+.  In the `d > 1` branch the reference keeps a dphidStrain left over from an earlier
 // Gauss point of its serial loop; there is no such thing on a GPU, cdS = 0 is used there (documented divergence).
-struct MicroOut { double d, dgphi, dphidd, cdS; };
+struct MicroOut { double d, dgphi, dphidd, cdS; bool stale; };
 __device__ __forceinline__ void micro_terms(const Params& P, double d, double& gn, double& gd, double& dg, double& ddg) {
   const double x = 1.0 - d;
   double dgn, ddgn;
-  if (P.ptype == 0)      { gn = x * x;                  dgn = -2.0 * x;           ddgn = 2.0; }
-  else if (P.ptype == 1) { const double sq = sqrt(x);
-                           gn = x * x * sq;             dgn = -2.5 * (x * sq);    ddgn = 2.5 * 1.5 * sq; }
-  else                   { const double x2 = x * x;
-                           gn = x2 * x2;                dgn = -4.0 * (x2 * x);    ddgn = 4.0 * 3.0 * x2; }
+  // p = 2: x*x, x, 1 are exact stand-ins for ::pow; p = 2.5 and p = 4 go through pow like the reference
+  // (MicroPhaseFractureModel.cpp:708-715): the Newton iteration stops at |Res| <= 1e-4, not at rounding level, so an
+  // ulp of difference in (1-d)^p would otherwise travel through the quotient-rule cancellations into K at a few 1e-12
+  if (P.ptype == 0)      { gn = x * x;                  dgn = -2.0 * x;               ddgn = 2.0; }
+  else if (P.ptype == 1) { gn = pow(x, 2.5);            dgn = -2.5 * pow(x, 1.5);     ddgn = 2.5 * 1.5 * pow(x, 0.5); }
+  else                   { gn = pow(x, 4.0);            dgn = -4.0 * pow(x, 3.0);     ddgn = 4.0 * 3.0 * pow(x, 2.0); }
   const double a12 = P.a1 * P.a2, a123 = a12 * P.a3;
   gd = gn + P.a1 * d + a12 * d * d + a123 * d * d * d;
   const double dgd  = dgn + P.a1 + 2.0 * a12 * d + 3.0 * a123 * d * d;
@@ -421,12 +422,12 @@ __device__ __forceinline__ double micro_newton(const Params& P, double Psi, doub
   const double ddw = 2.0 * (1.0 - P.eta);
   double gn, gd, dg, ddg;
   double d = micro_iterate(P, Psi, pf, dstart, dg, ddg);
-  o.dphidd = 0.0; o.cdS = 0.0;
+  o.dphidd = 0.0; o.cdS = 0.0; o.stale = false;
   if (d > d0) {
     const double den = ddg * Psi + P.gcl * ddw + P.alpha;
     o.cdS = -dg / den; o.dphidd = P.alpha / den;
   } else if (d < 0.0) d = 0.0;
-  else if (d > 1.0)   d = 1.0;
+  else if (d > 1.0)   { d = 1.0; o.stale = true; }     // the reference leaves dphidStrain as an earlier point set it (:772-776)
   else                d = d0;
   micro_terms(P, d, gn, gd, dg, ddg);
   o.d = d; o.dgphi = dg;
@@ -586,9 +587,12 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
           // (MicroPhaseFractureModel.cpp:535), so a point in tension finds K PVol once the serial loop has passed a
           // compression point (first_comp_kernel) and the array's initial contents -- zero assumed, as in the checker -- before.
           const double tr = (RANK == 3) ? (eps[0] + eps[1] + eps[RANK - 1]) : (eps[0] + eps[1] + 0.0);
+          // tension / compression of the point as the pre-pass classified it (one decision per call for every kernel path:
+          // this kernel's own tr may differ from the pre-pass's in the last bits and land on the other side of zero)
+          const bool comp = (P.comp_mask[ipoint / SH::NIP] >> (int)(ipoint % SH::NIP)) & 1u;
           double dd = 2.0 * P.G * (2.0 / 3.0), od = 2.0 * P.G * (-1.0 / 3.0);
           const double sh = 2.0 * P.G * 0.5;
-          if (tr > 0.0) { dd += P.Kb; od += P.Kb; }
+          if (!comp) { dd += P.Kb; od += P.Kb; }
           double psi2 = 0.0;
 #pragma unroll
           for (int i = 0; i < S; i++) {
@@ -601,7 +605,7 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
           }
           Psi = 0.5 * psi2;
           const double g = gfun(Psi, sp);
-          const double kn = (tr <= 0.0 || (unsigned long long)ipoint > *P.first_comp) ? P.Kb : 0.0;
+          const double kn = (comp || (unsigned long long)ipoint > *P.first_comp) ? P.Kb : 0.0;
           const double sn = kn * tr;
 #pragma unroll
           for (int i = 0; i < S; i++) {
@@ -633,6 +637,9 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
           }
         }
         r.d0 = r.d1 = r.d3 = 0.0;
+        // `d > 1` branch: cdS = 0 here, a stale dphidStrain in the reference -- counted, so that the divergence is never
+        // silent (fa_micro_stale_hits; reachable only with a committed d0 > 1)
+        if (mo.stale && write && P.stale_hits != nullptr) atomicAdd(P.stale_hits, 1ull);
         if (!ext) {
           const double coef = mo.dgphi * mo.cdS;        // second elemMat1 term: dgphi * sigma+ (x) dphidStrain (:816)
 #pragma unroll
@@ -1208,6 +1215,18 @@ __device__ __forceinline__ void stream_out(double* __restrict__ g, const double*
 // Same for the K image with 16-byte accesses: the image sits at s[0..n) with s - (base & 1) 16-byte aligned in LDS
 // and g = K + base, so that element i of the image is 16-byte aligned in LDS exactly when it is in HBM
 // (K itself 16-byte aligned, checked by the caller).  odd = base & 1.
+#ifndef FA_NT_STORE
+#define FA_NT_STORE 0
+#endif
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store16(double2* q, const double2 v) {
+#if FA_NT_STORE
+  d2v t; t.x = v.x; t.y = v.y;
+  __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(q));      // K is written once and never read by this kernel
+#else
+  *q = v;
+#endif
+}
 template <int BLK>
 __device__ __forceinline__ void stream_out16(double* __restrict__ g, const double* s, int n, int odd, bool overwrite) {
   const int tid = threadIdx.x;
@@ -1217,8 +1236,8 @@ __device__ __forceinline__ void stream_out16(double* __restrict__ g, const doubl
   const double2* s2 = (const double2*)(s + i0);
   int p = tid;
   if (overwrite) {
-    for (; p + BLK < npair; p += 2 * BLK) { const double2 a0 = s2[p], a1 = s2[p + BLK]; g2[p] = a0; g2[p + BLK] = a1; }
-    for (; p < npair; p += BLK) g2[p] = s2[p];
+    for (; p + BLK < npair; p += 2 * BLK) { const double2 a0 = s2[p], a1 = s2[p + BLK]; store16(g2 + p, a0); store16(g2 + p + BLK, a1); }
+    for (; p < npair; p += BLK) store16(g2 + p, s2[p]);
   } else {
     // accumulate: four reads of K in flight per lane before the first add (one at a time, every 32 bytes cost a full
     // memory round trip: 7.1 -> ms on cfg3)
@@ -1232,6 +1251,27 @@ __device__ __forceinline__ void stream_out16(double* __restrict__ g, const doubl
   }
   const int last = i0 + 2 * npair;
   if (last < n && tid == BLK - 1) { if (overwrite) g[last] = s[last]; else g[last] += s[last]; }
+}
+
+// FA_ACCUMULATE as the lane-pair kernel does it: the LDS image STARTS as the caller's K (and f) instead of zero -- the
+// reads are issued with the lane records, long before the first row block is added -- so the tile's contributions are
+// added on top in LDS and the write-out is the plain store stream of the overwrite mode: no read-modify-write round
+// trips at the end of the tile.  Same 16-byte alignment convention as stream_out16.
+template <int BLK>
+__device__ __forceinline__ void stream_in16(const double* __restrict__ g, double* s, int n, int odd) {
+  const int tid = threadIdx.x;
+  if (odd && tid == 0 && n > 0) s[0] = g[0];
+  const int i0 = odd, npair = (n - i0) >> 1;
+  const double2* __restrict__ g2 = (const double2*)(g + i0);
+  double2* s2 = (double2*)(s + i0);
+  int p = tid;
+  for (; p + 3 * BLK < npair; p += 4 * BLK) {
+    const double2 b0 = g2[p], b1 = g2[p + BLK], b2 = g2[p + 2 * BLK], b3 = g2[p + 3 * BLK];
+    s2[p] = b0; s2[p + BLK] = b1; s2[p + 2 * BLK] = b2; s2[p + 3 * BLK] = b3;
+  }
+  for (; p < npair; p += BLK) s2[p] = g2[p];
+  const int last = i0 + 2 * npair;
+  if (last < n && tid == BLK - 1) s[last] = g[last];
 }
 
 template <int BLOCKSZ>
@@ -1515,11 +1555,17 @@ __device__ __forceinline__ void swap_rec(const IpRec<SH, FAM, KEEP>& m, IpRec<SH
 #ifndef FA_PAIR_ATTR
 #define FA_PAIR_ATTR __attribute__((amdgpu_waves_per_eu(2)))
 #endif
+#ifndef FA_PAIR_ACC
+#define FA_PAIR_ACC 1          /* FA_ACCUMULATE passes of the lane-pair kernel initialise the LDS image from K (0: read-modify-write stream-out) */
+#endif
+#ifndef FA_PAIR_ACC_LDSTAB
+#define FA_PAIR_ACC_LDSTAB 1   /* ... with the shape tables from the LDS copy, like the overwrite kernel */
+#endif
 // LDSTAB: the lane's shape-table row comes from an LDS copy (per-lane address, a broadcast read); otherwise both
 // candidates come from scalar loads and are picked with selects.  Measured on cfg3 / cfg2 (MI355X, round 2): the LDS
 // copy wins for the u-phi matrix pass in overwrite mode (4.55 against 4.89 ms), the selects win for the accumulate
 // mode (7.06 / 7.40), with off-diagonal blocks (4.51 / 4.95) and for the elastic model (2.21 / 2.32).
-template <class SH, int FAM, bool WANT_K, bool KEEP, class SP, bool LDSTAB>
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP, bool LDSTAB, bool ACC = false>
 __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(const Params P) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, HALF = SH::NIP / 2, kBlock = SH::BLOCK, kLdsDoubles = SH::LDS;
   constexpr bool PF = (FAM != FAM_LE);
@@ -1567,10 +1613,18 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
 #pragma unroll
     for (int q = 0; q < LS / 4; q++) { const int4 v = rp4[q]; rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w; }
   }
-  if constexpr (WANT_K)
-    for (int i = tid; i < len; i += kBlock) sK[i] = 0.0;
-  for (int i = tid; i < nf; i += kBlock) sF[i] = 0.0;
-  __syncthreads();                                     // image zeroed: from here every wave adds as soon as it has computed
+  if constexpr (ACC) {                                 // FA_ACCUMULATE: the image starts as the caller's K / f (stream_in16)
+    if constexpr (WANT_K) {
+      if ((((uintptr_t)P.K) & 15) == 0) stream_in16<kBlock>(P.K + base, sK, len, odd);
+      else for (int i = tid; i < len; i += kBlock) sK[i] = P.K[base + i];
+    }
+    for (int i = tid; i < nf; i += kBlock) sF[i] = P.f[(int64_t)n0 * NDOF + i];
+  } else {
+    if constexpr (WANT_K)
+      for (int i = tid; i < len; i += kBlock) sK[i] = 0.0;
+    for (int i = tid; i < nf; i += kBlock) sF[i] = 0.0;
+  }
+  __syncthreads();                                     // image initialised: from here every wave adds as soon as it has computed
 
   RowBlock<SH, WANT_K, PF, KEEP> R;
   int32_t cn[NPE];
@@ -1659,10 +1713,10 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
   tr[7] = __builtin_readcyclecounter();
 #endif
   if constexpr (WANT_K) {
-    if ((((uintptr_t)P.K) & 15) == 0) stream_out16<kBlock>(P.K + base, sK, len, odd, P.overwrite);
-    else stream_out<kBlock>(P.K + base, sK, len, P.overwrite);
+    if ((((uintptr_t)P.K) & 15) == 0) stream_out16<kBlock>(P.K + base, sK, len, odd, ACC || P.overwrite);
+    else stream_out<kBlock>(P.K + base, sK, len, ACC || P.overwrite);
   }
-  stream_out<kBlock>(P.f + (int64_t)n0 * NDOF, sF, nf, P.overwrite);
+  stream_out<kBlock>(P.f + (int64_t)n0 * NDOF, sF, nf, ACC || P.overwrite);
 #ifdef FA_TRACE
   tr[4] = __builtin_readcyclecounter();
   __builtin_amdgcn_s_waitcnt(0);
@@ -1762,6 +1816,9 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
         using SP = decltype(spec);
         if constexpr (WANT_K && FAM == FAM_PF_ISO && !KEEP) {
           if (P.overwrite) { hipLaunchKernelGGL((assemble_rows_pair<SH, FAM, WANT_K, KEEP, SP, true>), dim3(grid), dim3(SH::BLOCK), 0, st, P); return; }
+        }
+        if constexpr (WANT_K) {                          // FA_ACCUMULATE: the image starts as K, the write-out is a store stream
+          if (!P.overwrite && FA_PAIR_ACC) { hipLaunchKernelGGL((assemble_rows_pair<SH, FAM, WANT_K, KEEP, SP, FA_PAIR_ACC_LDSTAB && FAM == FAM_PF_ISO && !KEEP, true>), dim3(grid), dim3(SH::BLOCK), 0, st, P); return; }
         }
         hipLaunchKernelGGL((assemble_rows_pair<SH, FAM, WANT_K, KEEP, SP, false>), dim3(grid), dim3(SH::BLOCK), 0, st, P);
       };

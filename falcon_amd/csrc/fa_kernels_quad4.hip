@@ -8,8 +8,8 @@ int launch_quad4_g2(const Params& P, int fam, bool want_K, bool keep, int path, 
   if (path == PATH_TILES) return launch_tiles_shape<Shape<2,4,4>>(P, fam, want_K, keep, grid, stream);
   return launch_shape<Shape<2,4,4>>(P, fam, want_K, keep, path, grid, stream);
 }
-int launch_first_comp_2d(const Params& P, int npe, int nip, unsigned long long* first, void* stream) {
-  return launch_first_comp_rank<2>(P, npe, nip, first, stream);
+int launch_first_comp_2d(const Params& P, int npe, int nip, unsigned long long* first, uint32_t* mask, void* stream) {
+  return launch_first_comp_rank<2>(P, npe, nip, first, mask, stream);
 }
 int launch_arc_func_2d(const Params& P, int npe, int nip, const double* state0, double* jac10, double* part, void* stream) {
   return launch_arc_func_rank<2>(P, npe, nip, state0, jac10, part, stream);

@@ -42,7 +42,12 @@ struct TileRec {                                        // offsets (doubles) ins
   static_assert(W == tile_rec_doubles(R, FAM, KEEP, SH::NPE), "host and device disagree on the record width");
 };
 
-template <class SH, int FAM, bool WANT_K, bool KEEP, class SP, int BLK>
+// ACC: the FA_ACCUMULATE variant of the GET_MATRIX0 kernels (the reference's `addBlock` +=, PhaseFractureModel.cpp:738-749).
+// A block's old values are requested together -- all row chunks of the block in flight at once, one memory round trip per
+// block instead of one per 32-byte chunk -- which costs registers the overwrite kernels must not pay (as a runtime branch
+// it slowed them from 5.3 to 7.7 ms on cfg4 at 128^3), hence a compile-time variant.  ACC = false serves FA_OVERWRITE and,
+// for the GET_INT_VECTOR passes, both modes.
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP, int BLK, bool ACC = false>
 __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, S = SH::S, STR = SH::STR;
   constexpr bool PF = (FAM != FAM_LE);
@@ -516,15 +521,24 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
 #else
           // a 24-byte row chunk as one 16-byte and one 8-byte store (the address is 8-byte aligned only; global memory
           // takes unaligned vector stores)
+          typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
           auto put3 = [&](long long b, const double (&v)[3]) {
-            typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
             double* q = P.K + b;
             if (P.overwrite) { d2u t; t.x = v[0]; t.y = v[1]; *reinterpret_cast<d2u*>(q) = t; q[2] = v[2]; }
             else { const d2u o = *reinterpret_cast<const d2u*>(q); d2u t; t.x = o.x + v[0]; t.y = o.y + v[1]; const double o2 = q[2];
                    *reinterpret_cast<d2u*>(q) = t; q[2] = o2 + v[2]; }
           };
+          if constexpr (ACC) {                           // both chunks' old values in flight together
+            double* qa = P.K + (sRow[ia] + (long long)i * 3 * sDeg[ia] + (long long)kpos * 3);
+            double* qb = diag ? qa : P.K + (sRow[ib] + (long long)i * 3 * sDeg[ib] + (long long)kpos2 * 3);
+            const d2u oa = *reinterpret_cast<const d2u*>(qa); const double oa2 = qa[2];
+            const d2u ob = *reinterpret_cast<const d2u*>(qb); const double ob2 = qb[2];
+            d2u t; t.x = oa.x + row[0]; t.y = oa.y + row[1]; *reinterpret_cast<d2u*>(qa) = t; qa[2] = oa2 + row[2];
+            if (!diag) { d2u u; u.x = ob.x + col[0]; u.y = ob.y + col[1]; *reinterpret_cast<d2u*>(qb) = u; qb[2] = ob2 + col[2]; }
+          } else {
           put3(sRow[ia] + (long long)i * 3 * sDeg[ia] + (long long)kpos * 3, row);
           if (!diag) put3(sRow[ib] + (long long)i * 3 * sDeg[ib] + (long long)kpos2 * 3, col);
+          }
 #endif
           if constexpr (FU_CAP) {
             if (fu) {                                  // f_a += K_ab u_b, f_b += K_ba u_a
@@ -746,6 +760,16 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
       if (NDOF == 4 && P.cnt[0] == 4 && P.cnt[3] == 4 && (reinterpret_cast<uintptr_t>(P.K) & 15) == 0) {
         if constexpr (NDOF == 4) {
           const long long b0 = sRow[io] + (long long)kp * 4, rs = (long long)sDeg[io] * 4;
+          if constexpr (ACC) {                           // the four row chunks' old values in flight together
+            double2 o0[4], o1[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const double2* q = reinterpret_cast<const double2*>(P.K + b0 + i * rs); o0[i] = q[0]; o1[i] = q[1]; }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              double2* q = reinterpret_cast<double2*>(P.K + b0 + i * rs);
+              q[0] = make_double2(o0[i].x + blk[i][0], o0[i].y + blk[i][1]); q[1] = make_double2(o1[i].x + blk[i][2], o1[i].y + blk[i][3]);
+            }
+          } else {
 #pragma unroll
           for (int i = 0; i < 4; i++) {
             double2* q = reinterpret_cast<double2*>(P.K + b0 + i * rs);
@@ -753,6 +777,21 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
             if (!P.overwrite) { const double2 o0 = q[0], o1 = q[1]; v0.x += o0.x; v0.y += o0.y; v1.x += o1.x; v1.y += o1.y; }
             q[0] = v0; q[1] = v1;
           }
+          }
+        }
+      } else if constexpr (ACC) {                        // every old value of the block first, then the stores
+        double old[NDOF][NDOF];
+#pragma unroll
+        for (int i = 0; i < NDOF; i++) {
+          const long long bi = row_base(io, i) + (long long)kp * P.cnt[i];
+#pragma unroll
+          for (int j = 0; j < NDOF; j++) { const int o = P.off[i][j]; old[i][j] = (o >= 0) ? P.K[bi + o] : 0.0; }
+        }
+#pragma unroll
+        for (int i = 0; i < NDOF; i++) {
+          const long long bi = row_base(io, i) + (long long)kp * P.cnt[i];
+#pragma unroll
+          for (int j = 0; j < NDOF; j++) { const int o = P.off[i][j]; if (o >= 0) P.K[bi + o] = old[i][j] + blk[i][j]; }
         }
       } else {
 #pragma unroll
@@ -837,9 +876,15 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   if (PF && P.err_part != nullptr) reduce_err<BLK>(err_acc, sErr, &P.err_part[tile]);
 }
 
+#ifndef FA_TILE_ACC
+#define FA_TILE_ACC 1
+#endif
 template <class SH, int FAM, bool WANT_K, bool KEEP, class SP, int BLK>
 static int launch_tiles_geom(const Params& P, int grid, hipStream_t st) {
-  auto kern = assemble_tiles<SH, FAM, WANT_K, KEEP, SP, BLK>;
+  auto kern = assemble_tiles<SH, FAM, WANT_K, KEEP, SP, BLK, false>;
+  if constexpr (WANT_K && FA_TILE_ACC) {
+    if (!P.overwrite && !P.tile_stage) kern = assemble_tiles<SH, FAM, WANT_K, KEEP, SP, BLK, true>;
+  }
   const size_t shmem = (size_t)P.tile_lds;
   if (shmem > 65536 - 64) {                            // per device and per context size: set on every launch (microseconds)
     hipError_t rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -1053,70 +1098,79 @@ __global__ __launch_bounds__(128) void arc_func_kernel(const Params P, int npe, 
 // MicroPhaseFracture* with AmorPhase: the reference's split material update writes stiffN only at Gauss points with
 // trace(strain) <= 0 (AmorPhaseMaterial.cpp:256-263) into an array that lives outside the model's element loop
 // (MicroPhaseFractureModel.cpp:535), so every later point of the serial loop in tension finds K PVol there.  One lane per
-// (element, Gauss point): the smallest serial index e * nip + ip of a compression point, by a 64-bit atomic minimum.
+// element: the sign of trace(strain) at each of its Gauss points goes into a bit mask (bit ip set: tr <= 0), and the
+// smallest serial index e * nip + ip of a compression point into `first` by a 64-bit atomic minimum.  The assembly
+// kernels -- whose strain arithmetic differs from path to path (unrolled sums, sym(F J^-1), ...) and could put a point
+// with tr of rounding size on the other side -- take the classification of every point from this mask, so ONE
+// computation decides tension / compression and the first compression point for the whole call.
 template <int RANK>
-__global__ __launch_bounds__(256) void first_comp_kernel(const Params P, int npe, int nip, unsigned long long* __restrict__ first) {
+__global__ __launch_bounds__(256) void first_comp_kernel(const Params P, int npe, int nip, unsigned long long* __restrict__ first,
+                                                         uint32_t* __restrict__ mask) {
   constexpr int ND = RANK + 1;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= P.nel * nip) return;
-  // workgroups start roughly in order: once an earlier point has been found the later ones have nothing to add
-  if ((unsigned long long)t >= *(volatile unsigned long long*)first) return;
-  const int64_t e = t / nip; const int ip = (int)(t - e * nip);
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P.nel) return;
   auto dof = [&](int64_t node, int k) -> int64_t { return P.node_dofs ? P.node_dofs[node * ND + k] : node * ND + k; };
-  const double* dn = P.tab + (size_t)nip * npe + (size_t)ip * npe * RANK;
   const int32_t* cn = P.conn + e * npe;
-  double J[RANK][RANK], inv[RANK][RANK];
-#pragma unroll
-  for (int i = 0; i < RANK; i++)
-#pragma unroll
-    for (int k = 0; k < RANK; k++) J[i][k] = 0.0;
-  for (int b = 0; b < npe; b++) {
-    const double* xb = P.coords + (int64_t)cn[b] * RANK;
+  uint32_t m = 0;
+  for (int ip = 0; ip < nip; ip++) {
+    const double* dn = P.tab + (size_t)nip * npe + (size_t)ip * npe * RANK;
+    double J[RANK][RANK], inv[RANK][RANK];
 #pragma unroll
     for (int i = 0; i < RANK; i++)
 #pragma unroll
-      for (int k = 0; k < RANK; k++) J[i][k] += xb[i] * dn[b * RANK + k];
-  }
-  if constexpr (RANK == 2) {
-    const double rd = 1.0 / (J[0][0] * J[1][1] - J[0][1] * J[1][0]);
-    inv[0][0] = J[1][1] * rd;  inv[0][1] = -J[0][1] * rd;
-    inv[1][0] = -J[1][0] * rd; inv[1][1] = J[0][0] * rd;
-  } else {
-    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-    const double rd = 1.0 / (J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02);
-    inv[0][0] = c00 * rd;
-    inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
-    inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * rd;
-    inv[1][0] = c01 * rd;
-    inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * rd;
-    inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rd;
-    inv[2][0] = c02 * rd;
-    inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
-    inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
-  }
-  double en[RANK];                                     // the normal strains, summed over the nodes as ip_point_core does
+      for (int k = 0; k < RANK; k++) J[i][k] = 0.0;
+    for (int b = 0; b < npe; b++) {
+      const double* xb = P.coords + (int64_t)cn[b] * RANK;
 #pragma unroll
-  for (int i = 0; i < RANK; i++) en[i] = 0.0;
-  for (int b = 0; b < npe; b++) {
+      for (int i = 0; i < RANK; i++)
 #pragma unroll
-    for (int i = 0; i < RANK; i++) {
-      double g = 0.0;
-#pragma unroll
-      for (int k = 0; k < RANK; k++) g += dn[b * RANK + k] * inv[k][i];
-      en[i] += g * P.state[dof(cn[b], i)];
+        for (int k = 0; k < RANK; k++) J[i][k] += xb[i] * dn[b * RANK + k];
     }
+    if constexpr (RANK == 2) {
+      const double rd = 1.0 / (J[0][0] * J[1][1] - J[0][1] * J[1][0]);
+      inv[0][0] = J[1][1] * rd;  inv[0][1] = -J[0][1] * rd;
+      inv[1][0] = -J[1][0] * rd; inv[1][1] = J[0][0] * rd;
+    } else {
+      const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+      const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+      const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+      const double rd = 1.0 / (J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02);
+      inv[0][0] = c00 * rd;
+      inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
+      inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * rd;
+      inv[1][0] = c01 * rd;
+      inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * rd;
+      inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rd;
+      inv[2][0] = c02 * rd;
+      inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
+      inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
+    }
+    double en[RANK];                                   // the normal strains, summed over the nodes as ip_point_core does
+#pragma unroll
+    for (int i = 0; i < RANK; i++) en[i] = 0.0;
+    for (int b = 0; b < npe; b++) {
+#pragma unroll
+      for (int i = 0; i < RANK; i++) {
+        double g = 0.0;
+#pragma unroll
+        for (int k = 0; k < RANK; k++) g += dn[b * RANK + k] * inv[k][i];
+        en[i] += g * P.state[dof(cn[b], i)];
+      }
+    }
+    const double tr = (RANK == 3) ? (en[0] + en[1] + en[RANK - 1]) : (en[0] + en[1] + 0.0);
+    if (tr <= 0.0) m |= 1u << ip;
   }
-  const double tr = (RANK == 3) ? (en[0] + en[1] + en[RANK - 1]) : (en[0] + en[1] + 0.0);
-  if (tr <= 0.0 && (unsigned long long)t < *(volatile unsigned long long*)first) atomicMin(first, (unsigned long long)t);
+  mask[e] = m;
+  if (m != 0u) {
+    const unsigned long long t = (unsigned long long)(e * nip + (__ffs((int)m) - 1));
+    if (t < *(volatile unsigned long long*)first) atomicMin(first, t);
+  }
 }
 
 template <int RANK>
-static int launch_first_comp_rank(const Params& P, int npe, int nip, unsigned long long* first, void* stream) {
-  const int64_t n = P.nel * nip;
-  if (n <= 0) return 0;
-  hipLaunchKernelGGL(first_comp_kernel<RANK>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, npe, nip, first);
+static int launch_first_comp_rank(const Params& P, int npe, int nip, unsigned long long* first, uint32_t* mask, void* stream) {
+  if (P.nel <= 0) return 0;
+  hipLaunchKernelGGL(first_comp_kernel<RANK>, dim3((unsigned)((P.nel + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, npe, nip, first, mask);
   return (int)hipGetLastError();
 }
 

@@ -33,7 +33,16 @@ enum { FA_TRI3_G1 = 0, FA_TRI3_G3 = 1, FA_QUAD4_G2 = 2, FA_QUAD8_G3 = 3, FA_QUAD
 /* ModelFactory names, src/fem/solidmech/FalconSolidMechModels.cpp:10-22 */
 enum { FA_LINEAR_ELASTICITY = 0, FA_PHASE_FRACTURE = 1, FA_PHASE_FRACTURE_EXT = 2, FA_PHASE_FRACTURE_EXTIT = 3,
        FA_MICRO_PHASE_FRACTURE = 4, /* "MicroPhaseFracture": micromorphic variant, MicroPhaseFractureModel.cpp:502-851;
-                                      history = local damage d (preHist_.phasef_), penalty default 250 */
+                                      history = local damage d (preHist_.phasef_), penalty default 250.
+                                      With FA_AMOR_PHASE (all three micromorphic models) the reference's split update reads
+                                      stiffN from an array it fills at compression points only and never resets
+                                      (AmorPhaseMaterial.cpp:256-263, MicroPhaseFractureModel.cpp:535): a point in tension
+                                      gets K PVol once the element loop has passed a compression point and the array's
+                                      initial contents before.  Jem does not initialise that array -- the reference is
+                                      undefined there; this library ASSUMES ZERO.  Consequences the caller must know: K and
+                                      f_int depend on the serial element numbering (through the first compression point of
+                                      the call) and on the partition (every context / rank finds its own first compression
+                                      point), exactly as the reference's would.  FA_VERBOSE=1 prints this at fa_create. */
        FA_MICRO_PHASE_FRACTURE_EXT = 5,   /* "MicroPhaseFractureExt", MicroPhaseFractureExtModel.cpp:523-952: g from
                                       the damage solved for the extrapolated micromorphic variable; the caller passes
                                       stateExt_ (:553-566) as state00; state0 / dt / dt0 are not read; penalty 6500 */
@@ -53,6 +62,11 @@ enum { FA_HOOKE = 0, FA_AMOR_PHASE = 1, FA_BOURDIN_PHASE = 2, FA_MIEHE_PHASE = 3
                         "vonMises" is refused in 2-D: its derivative is a 6-vector whatever the strain size (:677-683),
                         used out of bounds at GradientDamageModel.cpp:548 */ };
 
+/* Device-side limits of FA_DAMAGE, checked by fa_create and stricter than DamageMaterial::configure (which takes any
+ * value >= 0): kappaI > 0 always (omega divides by kappa); kappaC > kappaI for linear1 / linear2 / exponential2 / power /
+ * polynomial; b >= 0 (hyperbolic); kappaC > 0 and s >= 0 (expoEnergy); kappaC > kappaP >= 0 (multilinear); eta > 0 with
+ * eqvStrain = vonMises.  A property set the reference accepts at configure and that violates one of these is refused
+ * with FA_ERR_ARG here (the reference would divide by zero later, at the first update). */
 /* eqvStrain of the Damage material */
 enum { FA_EQV_ENERGY = 0, FA_EQV_MAZARS = 1, FA_EQV_VONMISES = 2 /* 3-D shapes only, needs eta */ };
 
@@ -199,6 +213,12 @@ fa_status fa_commit(fa_ctx* ctx);
 fa_status fa_get_history(const fa_ctx* ctx, int32_t which, double* host_out);
 fa_status fa_set_history(fa_ctx* ctx, int32_t which, const double* host_in);
 double*   fa_history_device(fa_ctx* ctx, int32_t which);
+/* MicroPhaseFracture*: number of Gauss points of the last fa_assemble call that took the `d > 1` branch of the local
+ * damage update (MicroPhaseFractureModel.cpp:772-776).  There the reference keeps a dphidStrain left over from an earlier
+ * Gauss point of its serial loop; the kernels use 0.  The branch needs a committed d0 > 1, so the count is 0 in any
+ * physical run -- a non-zero value says that K of this call differs from the reference's.  Waits for the call to finish.
+ * *out = 0 for every other model. */
+fa_status fa_micro_stale_hits(const fa_ctx* ctx, int64_t* out);
 /* strain_ cache, (str[+1]) x nip_total, column = ipoint (PhaseFractureModel.cpp:187); filled by calls
  * made with FA_STORE_STRAIN. */
 fa_status fa_get_strain_cache(const fa_ctx* ctx, double* host_out);
