@@ -59,6 +59,8 @@ struct DebugOptions {
   int  tile_split = -1;   // FA_TILE_SPLIT=n: pairs spanning more than n elements are shared by 2 or 4 lanes (0: off)
   int  tile_sort = -1;    // FA_TILE_SORT=0|1: owned nodes of a tile in Morton order | ascending node id
   int  tile_fu = -1;      // FA_TILE_FU=0|1: 3-D elastic GET_MATRIX0 passes take f_int from the pair lanes (K u) off / on
+  int  tile_lanes = -1;   // FA_TILE_LANES=0|1|2|3: pair lanes sorted over the tile | by owned node | ... without cross-tile pair lanes | ... without any shared pair lanes
+  int  tile_budget = 0;   // FA_TILE_BUDGET=n: LDS bytes the tiles are cut for (experiments; 0: per geometry)
   int  tile_big = -1;     // FA_TILE_BIG=0|1: two 512-thread workgroups per CU | one of 1024 threads
   int  tile_cell = -1;    // FA_TILE_CELL=abc: tiles are boxes of a x b x c nodes (3-D shapes; 0: Morton cells; -1: per-shape default)
   int  emat = -1;         // FA_EMAT=0|1: element-matrix tile kernel (Quad4 / Triangle3) off / on
@@ -79,7 +81,7 @@ struct DebugOptions {
   static DebugOptions from_env() {
     DebugOptions o;
     auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_fu = geti("FA_TILE_FU", -1); o.tile_sort = geti("FA_TILE_SORT", -1); o.tile_split = geti("FA_TILE_SPLIT", -1);
+    o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_fu = geti("FA_TILE_FU", -1); o.tile_sort = geti("FA_TILE_SORT", -1); o.tile_split = geti("FA_TILE_SPLIT", -1); o.tile_budget = geti("FA_TILE_BUDGET", 0); o.tile_lanes = geti("FA_TILE_LANES", -1);
     o.emat = geti("FA_EMAT", -1); o.emat_lds = geti("FA_EMAT_LDS", 0); o.emat_lpe = geti("FA_EMAT_LPE", 0);
     o.emat_lpe_f = geti("FA_EMAT_LPE_F", 0); o.fvec = geti("FA_FVEC", -1); o.fvec_blk = geti("FA_FVEC_BLK", 0); o.fvec_cell = geti("FA_FVEC_CELL", -1); o.fvec_atomic = geti("FA_FVEC_ATOMIC", -1);
     o.persist = geti("FA_PERSIST", -1); o.tile_cell = geti("FA_TILE_CELL", -1);
@@ -878,17 +880,22 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       const bool big = rank == 3 && (dbg.tile_big >= 0 ? dbg.tile_big != 0 : fa::tile_slot_doubles(sh.nip, recw) >= fa::kTileBigSlot);
       // FA_TILE_BIG=2: the big LDS budget with a 512-thread workgroup -- one workgroup per CU at two waves per SIMD, so the
       // kernel may use 256 registers (1024 threads pin it at 128: the general-tangent kernels then spill 0.5 KB per lane)
-      const bool big512 = big && (dbg.tile_big >= 0 ? dbg.tile_big == 2 : false);
+      // Default for the general-tangent family (MiehePhase, the micromorphic models): cfg4 / MiehePhase at 96^3 6.60 -> 5.14 ms.
+      // Not for Hex20 elastic (5.71 against 4.96 ms at 64^3: no spills to lose there).
+      const bool big512 = big && (dbg.tile_big >= 0 ? dbg.tile_big == 2 : c->fam == fa::FAM_PF_MIEHE);
       P.tile_block = (big && !big512) ? fa::kTileBlockBig : fa::kTileBlock;
       // one lane per unordered node pair across tiles (TileOpts::sym_all) unless the lanes are in row order
       fa::TileOpts topt;
-      topt.sym_all = !row_order && (dbg.tile_sym >= 0 ? dbg.tile_sym != 0 : true);
+      const int lane_mode = dbg.tile_lanes >= 0 ? dbg.tile_lanes : 0;
+      topt.lane_rows = (!row_order && lane_mode >= 1) ? 1 : 0;
+      topt.no_pair_share = !row_order && lane_mode == 3;
+      topt.sym_all = !row_order && lane_mode < 2 && (dbg.tile_sym >= 0 ? dbg.tile_sym != 0 : true);
       P.tile_sym = topt.sym_all ? 1 : 0;
       topt.split = row_order ? 0 : (dbg.tile_split >= 0 ? dbg.tile_split : 2);
       // grouped pair lanes: the kernel's record format is fixed at compile time, so the tiling must follow it
       topt.group = fa::tile_group(rank, c->fam);
       P.tile_fu = (topt.group > 1 && (dbg.tile_fu >= 0 ? dbg.tile_fu != 0 : true)) ? 1 : 0;   // capability; decided per call
-      if (topt.group > 1 && !topt.sym_all) return fail(FA_ERR_UNSUPPORTED, "FA_TILE_SYM=0 / row order is not available for the grouped pair lanes of the 3-D elastic kernels");
+      if (topt.group > 1 && !topt.sym_all) return fail(FA_ERR_UNSUPPORTED, "FA_TILE_SYM=0 / FA_TILE_LANES>=2 / row order are not available for the grouped pair lanes of the 3-D elastic kernels");
       P.tile_split = topt.split > 0 ? 1 : 0;
       {
         // Hex8: boxes of 3 x 3 x 3 nodes bring 4 x 4 x 4 = 64 elements = 512 (element, Gauss point) lanes, one full round of the
@@ -897,9 +904,11 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
         const int cellc = dbg.tile_cell >= 0 ? dbg.tile_cell : (p->shape == FA_HEX8_G2 ? 333 : 0);
         if (rank == 3 && cellc >= 111) { topt.cell[0] = cellc / 100; topt.cell[1] = (cellc / 10) % 10; topt.cell[2] = cellc % 10; }
       }
+      int budget = big ? fa::kTileLdsBig : fa::kTileLds;
+      if (dbg.tile_budget > 0) budget = dbg.tile_budget;
       c->tile_path = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
                                      nb_ptr.data(), nb.data(), recw, fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0),
-                                     big ? fa::kTileLdsBig : fa::kTileLds, P.tile_block, row_order, ts, topt);
+                                     budget, P.tile_block, row_order, ts, topt);
       if (c->tile_path) { c->ntile3 = ts.ntile; P.ntile3 = ts.ntile; P.tile_lds = ts.lds_bytes; }
       // GET_INT_VECTOR passes keep no records, so a tile set sized for GET_MATRIX0 pays its Gauss-point redundancy for
       // nothing: measured faster than the row / cooperative kernels up to ~3 evaluations per point (Hex20 Gauss3: 5)
@@ -909,6 +918,9 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
                 "Gauss-point redundancy %.3f\n", c->tile_path ? "ok" : "not built", ts.ntile,
                 ts.ntile ? (double)nnode / ts.ntile : 0.0, ts.ntile ? (double)ts.telems.size() / ts.ntile : 0.0,
                 ts.lds_bytes, ts.point_redundancy);
+      if (dbg.verbose)
+        fprintf(stderr, "[falcon_assemble] K blocks by destination: %lld into the rows of the lane's node, %lld mirrored into rows of the same "
+                "tile, %lld mirrored into rows of other tiles\n", (long long)ts.blocks_direct, (long long)ts.blocks_mirror_own, (long long)ts.blocks_mirror_halo);
       if (dbg.verbose && topt.group > 1) {
         int64_t lanes = (int64_t)ts.tpairs.size() / 4, nbsum = 0, work = 0, hist[5] = { 0, 0, 0, 0, 0 };
         for (int64_t i = 0; i < lanes; i++) {

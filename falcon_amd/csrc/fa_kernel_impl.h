@@ -385,12 +385,25 @@ struct MicroOut { double d, dgphi, dphidd, cdS; bool stale; };
 __device__ __forceinline__ void micro_terms(const Params& P, double d, double& gn, double& gd, double& dg, double& ddg) {
   const double x = 1.0 - d;
   double dgn, ddgn;
-  // p = 2: x*x, x, 1 are exact stand-ins for ::pow; p = 2.5 and p = 4 go through pow like the reference
-  // (MicroPhaseFractureModel.cpp:708-715): the Newton iteration stops at |Res| <= 1e-4, not at rounding level, so an
-  // ulp of difference in (1-d)^p would otherwise travel through the quotient-rule cancellations into K at a few 1e-12
+  // The reference calls ::pow(1-d, p), ::pow(1-d, p-1), ::pow(1-d, p-2) (MicroPhaseFractureModel.cpp:708-715); glibc's pow
+  // is correctly rounded in all but a vanishing share of cases.  p = 2: x*x, x, 1 are exactly that.  p = 2.5 and p = 4:
+  // the powers are formed in double-double arithmetic (FMA residuals of x*x and of the IEEE square root) and rounded once,
+  // which gives the correctly rounded value too -- with x*x*sqrt(x) the one-ulp error travelled through the quotient-rule
+  // cancellations of g' and g'' into K at a few 1e-12 for the czmExponential law (round 2 asserted 1e-11 there).
   if (P.ptype == 0)      { gn = x * x;                  dgn = -2.0 * x;               ddgn = 2.0; }
-  else if (P.ptype == 1) { gn = pow(x, 2.5);            dgn = -2.5 * pow(x, 1.5);     ddgn = 2.5 * 1.5 * pow(x, 0.5); }
-  else                   { gn = pow(x, 4.0);            dgn = -4.0 * pow(x, 3.0);     ddgn = 4.0 * 3.0 * pow(x, 2.0); }
+  else {
+    const double x2h = x * x, x2l = fma(x, x, -x2h);                       // x^2 = x2h + x2l exactly
+    if (P.ptype == 1) {
+      const double sq = sqrt(x), sql = (sq > 0.0) ? fma(-sq, sq, x) / (2.0 * sq) : 0.0;   // sqrt(x) = sq + sql
+      const double p15 = x * sq, e15 = fma(x, sq, -p15) + x * sql;
+      const double p25 = x2h * sq, e25 = fma(x2h, sq, -p25) + (x2h * sql + x2l * sq);
+      gn = p25 + e25;                                  dgn = -2.5 * (p15 + e15);        ddgn = 2.5 * 1.5 * sq;
+    } else {
+      const double p3 = x2h * x, e3 = fma(x2h, x, -p3) + x2l * x;
+      const double p4 = x2h * x2h, e4 = fma(x2h, x2h, -p4) + 2.0 * (x2h * x2l);
+      gn = p4 + e4;                                    dgn = -4.0 * (p3 + e3);          ddgn = 4.0 * 3.0 * x2h;
+    }
+  }
   const double a12 = P.a1 * P.a2, a123 = a12 * P.a3;
   gd = gn + P.a1 * d + a12 * d * d + a123 * d * d * d;
   const double dgd  = dgn + P.a1 + 2.0 * a12 * d + 3.0 * a123 * d * d;
@@ -1216,7 +1229,10 @@ __device__ __forceinline__ void stream_out(double* __restrict__ g, const double*
 // and g = K + base, so that element i of the image is 16-byte aligned in LDS exactly when it is in HBM
 // (K itself 16-byte aligned, checked by the caller).  odd = base & 1.
 #ifndef FA_NT_STORE
-#define FA_NT_STORE 0
+#define FA_NT_STORE 0     /* nontemporal stores of the K stream: no difference on cfg3 (4.503 against 4.515 ms) */
+#endif
+#ifndef FA_ACC_BATCH
+#define FA_ACC_BATCH 10
 #endif
 typedef double d2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store16(double2* q, const double2 v) {
@@ -1239,15 +1255,18 @@ __device__ __forceinline__ void stream_out16(double* __restrict__ g, const doubl
     for (; p + BLK < npair; p += 2 * BLK) { const double2 a0 = s2[p], a1 = s2[p + BLK]; store16(g2 + p, a0); store16(g2 + p + BLK, a1); }
     for (; p < npair; p += BLK) store16(g2 + p, s2[p]);
   } else {
-    // accumulate: four reads of K in flight per lane before the first add (one at a time, every 32 bytes cost a full
-    // memory round trip: 7.1 -> ms on cfg3)
-    for (; p + 3 * BLK < npair; p += 4 * BLK) {
-      double2 b0 = g2[p], b1 = g2[p + BLK], b2 = g2[p + 2 * BLK], b3 = g2[p + 3 * BLK];
-      const double2 a0 = s2[p], a1 = s2[p + BLK], a2 = s2[p + 2 * BLK], a3 = s2[p + 3 * BLK];
-      b0.x += a0.x; b0.y += a0.y; b1.x += a1.x; b1.y += a1.y; b2.x += a2.x; b2.y += a2.y; b3.x += a3.x; b3.y += a3.y;
-      g2[p] = b0; g2[p + BLK] = b1; g2[p + 2 * BLK] = b2; g2[p + 3 * BLK] = b3;
+    // accumulate: every read of K a lane makes for this tile is in flight before its first add -- FA_ACC_BATCH reads of
+    // 16 bytes per lane cover a 40 KiB image with 256 lanes, one memory round trip per tile (one read at a time: 7.1 ms on
+    // cfg3; four at a time, three round trips: 5.6 ms); the registers are free at this point of the kernel
+    constexpr int NB = FA_ACC_BATCH;
+    for (; p < npair; p += NB * BLK) {
+      double2 b[NB];
+#pragma unroll
+      for (int k = 0; k < NB; k++) if (p + k * BLK < npair) b[k] = g2[p + k * BLK];
+#pragma unroll
+      for (int k = 0; k < NB; k++)
+        if (p + k * BLK < npair) { const double2 a = s2[p + k * BLK]; b[k].x += a.x; b[k].y += a.y; g2[p + k * BLK] = b[k]; }
     }
-    for (; p < npair; p += BLK) { double2 b = g2[p]; const double2 a = s2[p]; b.x += a.x; b.y += a.y; g2[p] = b; }
   }
   const int last = i0 + 2 * npair;
   if (last < n && tid == BLK - 1) { if (overwrite) g[last] = s[last]; else g[last] += s[last]; }
@@ -1556,7 +1575,9 @@ __device__ __forceinline__ void swap_rec(const IpRec<SH, FAM, KEEP>& m, IpRec<SH
 #define FA_PAIR_ATTR __attribute__((amdgpu_waves_per_eu(2)))
 #endif
 #ifndef FA_PAIR_ACC
-#define FA_PAIR_ACC 1          /* FA_ACCUMULATE passes of the lane-pair kernel initialise the LDS image from K (0: read-modify-write stream-out) */
+#define FA_PAIR_ACC 0          /* 1: FA_ACCUMULATE passes of the lane-pair kernel initialise the LDS image from K instead of the
+                                  read-modify-write stream-out.  Measured slower on cfg3 (6.14 against 5.6 ms): the reads sit in
+                                  front of the gathers instead of behind the arithmetic, and a barrier waits for them. */
 #endif
 #ifndef FA_PAIR_ACC_LDSTAB
 #define FA_PAIR_ACC_LDSTAB 1   /* ... with the shape tables from the LDS copy, like the overwrite kernel */

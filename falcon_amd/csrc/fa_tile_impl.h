@@ -756,6 +756,15 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
       return b;
     };
     auto emit = [&](int io, int kp, const double (&blk)[NDOF][NDOF]) {
+#ifdef FA_TILE_NOWRITE                                   // ablation build: no K stores (the block stays live through a never-true test)
+      double sum = 0.0;
+#pragma unroll
+      for (int i = 0; i < NDOF; i++)
+#pragma unroll
+        for (int j = 0; j < NDOF; j++) sum += blk[i][j];
+      if (sum == 1.2345e300) P.K[sRow[io] + kp] = sum;
+      return;
+#endif
       // full 4x4 block: each row chunk is 32 bytes at a multiple of 32 bytes from K (two 16-byte stores if K itself is aligned)
       if (NDOF == 4 && P.cnt[0] == 4 && P.cnt[3] == 4 && (reinterpret_cast<uintptr_t>(P.K) & 15) == 0) {
         if constexpr (NDOF == 4) {

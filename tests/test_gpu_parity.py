@@ -403,7 +403,8 @@ ALL_SHAPES = [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2] + HIGH_ORDER
 
 
 def run_micro(shape, material, keep, *, flags=capi.OVERWRITE, want_K=True, commit=False, frac=capi.AT2, sigma_t=0.0,
-              young=210.0, gc=2.7e-3, l0=0.2, tol=TOL, model=capi.MICRO_PHASE_FRACTURE, beta=250.0, state_mod=None):
+              young=210.0, gc=2.7e-3, l0=0.2, tol=TOL, model=capi.MICRO_PHASE_FRACTURE, beta=250.0, state_mod=None,
+              tol_K=None):
     import torch
     coords, conn, st, kw, cfg = make_case(shape, model, material, keep, frac=frac, sigma_t=sigma_t,
                                           young=young, gc=gc, l0=l0)
@@ -437,7 +438,7 @@ def run_micro(shape, material, keep, *, flags=capi.OVERWRITE, want_K=True, commi
     loading = (ref["hist_new"] > d0).mean()
     assert 0.05 < loading < 0.95                                  # both branches of :738-782 are exercised
     if want_K:
-        assert rel_rowmax_err(rp, K.cpu().numpy(), ref["K"]) < tol
+        assert rel_rowmax_err(rp, K.cpu().numpy(), ref["K"]) < (tol if tol_K is None else tol_K)
     assert vec_err(f.cpu().numpy(), ref["f"]) < tol
     assert np.abs(asm.get_history(1) - ref["hist_new"]).max() < tol
     assert np.abs(asm.get_strain_cache() - ref["strain"]).max() < tol * np.abs(ref["strain"]).max()
@@ -457,12 +458,22 @@ def test_micro_phase_fracture(shape, material):
     run_micro(shape, material, keep=0, want_K=False)
 
 
+# czmHyperbolic (p = 4) at this state is nearly fully degraded: the consistent tangent g DP + DN - g'^2 / J sigma+ (x) sigma+
+# (MicroPhaseFractureModel.cpp:804-816) is the difference of two terms that almost cancel, so K1 is ill-conditioned with
+# respect to one-ulp changes upstream (Psi from MiehePhase's projector).  Measured, not guessed: the checker compiled with
+# and without FMA contraction differs from ITSELF by 2.2e-12 on exactly this case and by < 6e-13 on the two others
+# (tests/test_oracle_kat.py::test_micro_law_conditioning pins those numbers on the CPU), so 1e-12 is not a bar any two
+# compilations of the reference's own source would meet there; f_int, the damage and the strain cache are held to 1e-12.
+MICRO_LAW_TOL_K = {capi.AT1: TOL, capi.CZM_EXPONENTIAL: TOL, capi.CZM_HYPERBOLIC: 5e-12}
+
+
 @pytest.mark.parametrize("frac", [capi.AT1, capi.CZM_EXPONENTIAL, capi.CZM_HYPERBOLIC])
 def test_micro_fracture_laws(frac):
-    """The local Newton iteration runs through (1-d)^p with p = 2.5 / 4: ::pow on both sides, as the reference calls it
-    (MicroPhaseFractureModel.cpp:708-715) -- with sqrt / squares on the device the iteration, which stops at |Res| <= 1e-4
-    and not at rounding level, carried an ulp of difference into K at a few 1e-12 (round 2 asserted 1e-11 here)."""
-    run_micro(capi.QUAD4_G2, capi.MIEHE_PHASE, keep=1, frac=frac, sigma_t=3.0, young=3e4, gc=0.12, l0=0.25)
+    """The local Newton iteration runs through (1-d)^p with p = 2.5 / 4: ::pow in the reference
+    (MicroPhaseFractureModel.cpp:708-715), correctly rounded double-double powers on the device -- with x*x*sqrt(x) the
+    czmExponential law missed 1e-12 (round 2 asserted 1e-11 for all three laws)."""
+    run_micro(capi.QUAD4_G2, capi.MIEHE_PHASE, keep=1, frac=frac, sigma_t=3.0, young=3e4, gc=0.12, l0=0.25,
+              tol_K=MICRO_LAW_TOL_K[frac])
 
 
 def test_micro_stale_branch_is_counted():
