@@ -7,8 +7,11 @@ over the whole synthetic mesh, inputs resident in HBM.  N=1 workload = BASELINE.
 into N blocks of element layers along its last axis (strips of the Quad4 meshes, slabs of the Hex8 cube;
 falcon_amd/distributed.py), one per GPU; every step ends with the interface exchange over RCCL -- the f_int
 halo-sum and, with --k-halo reduce, the interface rows of K sent to their owner (the lower rank).
---scaling weak (default): every GPU gets a full-size block (N x the BASELINE mesh in total); --scaling strong:
-the one BASELINE mesh is divided among the GPUs.  value = all ranks' elements / max time over ranks.
+--scaling strong (default for N > 1: BASELINE.json quotes the metric on ONE 16 M element mesh "at 1/2/4/8 MI355X"): the one
+BASELINE mesh is divided among the GPUs; --scaling weak: every GPU gets a full-size block (N x the BASELINE mesh in
+total).  value = all ranks' elements / max time over ranks.  Every rank assembles the node tiles that own an interface node
+first, on a side stream, and posts their rows to the neighbours while the interior tiles run (falcon_amd.distributed.
+OverlappedStep; --no-overlap: assemble, then exchange).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5|cfg5g2|cfg3micro] [--n SIZE]
                     [--material amor|miehe|bourdin] [--keep-off-diags] [--mode ...] [--pattern ...] [--force-only]
@@ -162,17 +165,20 @@ def main():
     ap.add_argument("--material", default="amor", choices=["amor", "miehe", "bourdin", "amor-split"])
     ap.add_argument("--keep-off-diags", action="store_true")
     ap.add_argument("--force-only", action="store_true", help="GET_INT_VECTOR pass instead of GET_MATRIX0")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: one full-size block per GPU | the one mesh divided")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: the one mesh divided (default) | one full-size block per GPU")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: assemble the whole block, then exchange (no interface-first split)")
     ap.add_argument("--k-halo", default="additive", choices=["additive", "reduce"],
                     help="N > 1: leave the subdomain matrices additive (Jive's distributed representation) | send the interface rows of K to the lower rank")
     ap.add_argument("--no-f-int-only", action="store_true", help="skip the extra GET_INT_VECTOR measurement (profiler passes: one kernel per run)")
     ap.add_argument("--cpu-elems", type=int, default=6250000, help="elements in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
 
     import torch
     import torch.distributed as dist
     from falcon_amd import capi, meshgen
-    from falcon_amd.distributed import InterfacePlanK, SlabPartition, halo_sum, halo_sum_K
+    from falcon_amd.distributed import InterfacePlanK, OverlappedStep, SlabPartition, halo_sum, halo_sum_K
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -230,7 +236,14 @@ def main():
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
+    stepper = None
+    if part is not None and not args.no_overlap:
+        stepper = OverlappedStep(asm, part, plan, capi=capi, device=dev)
+
     def step():
+        if stepper is not None:
+            stepper.step(state, K, f, flags)
+            return
         asm.assemble(state, K, f, flags=flags)
         if part is not None:
             halo_sum(f, part)
@@ -249,6 +262,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
+        if stepper is not None:
+            stepper.step(state, K, f, flags)          # interface tiles + exchange on the side stream, interior here
+            ev[i][1].record()                         # (N > 1: the events bracket the whole overlapped step)
+            continue
         asm.assemble(state, K, f, flags=flags)
         ev[i][1].record()
         if part is not None:
@@ -302,7 +319,8 @@ def main():
             "config": {"workload": wl["desc"], "elements_per_gpu": asm.nel, "ndof_per_gpu": asm.ndof,
                        "nnz_per_gpu": asm.nnz, "mode": args.mode, "pattern": args.pattern,
                        "partition": (f"{world} blocks of element layers along the last axis ({args.scaling} scaling), f_int interface "
-                                     f"halo-sum over RCCL, K {'interface rows reduced to the lower rank' if plan is not None else 'additive'}")
+                                     f"halo-sum over RCCL, K {'interface rows reduced to the lower rank' if plan is not None else 'additive'}, "
+                                     f"{'interface tiles first, exchange overlapped with the interior' if stepper is not None else 'assemble then exchange'}")
                                     if world > 1 else "single GPU",
                        "setup_seconds": round(t_setup, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

@@ -23,6 +23,7 @@ PLANE_STRAIN, PLANE_STRESS = 0, 1
 AT1, AT2, CZM_LINEAR, CZM_EXPONENTIAL, CZM_CORNELISSEN, CZM_HYPERBOLIC = range(6)
 PATTERN_FULL, PATTERN_WRITTEN = 0, 1
 ACCUMULATE, OVERWRITE, STORE_STRAIN, FORCE_GENERIC, DETERMINISTIC = 0, 1, 2, 4, 8
+PART_INTERFACE, PART_INTERIOR = 16, 32
 
 SHAPE_INFO = {  # shape id -> (rank, npe, nip)
     TRI3_G1: (2, 3, 1), TRI3_G3: (2, 3, 3), QUAD4_G2: (2, 4, 4), QUAD8_G3: (2, 8, 9), QUAD8_G2: (2, 8, 4),
@@ -60,7 +61,7 @@ EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_
            "fa_assemble", "fa_assemble_noalloc", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
            "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum", "fa_strain_table", "fa_stress_table",
            "fa_pattern_device32", "fa_device", "fa_cons_create", "fa_cons_destroy", "fa_cons_set_rvalues", "fa_cons_eliminate",
-           "fa_cons_eval_masters", "fa_cons_eval_slaves", "fa_residual", "fa_arc_func", "fa_output_data", "fa_micro_stale_hits"]
+           "fa_cons_eval_masters", "fa_cons_eval_slaves", "fa_residual", "fa_arc_func", "fa_output_data", "fa_micro_stale_hits", "fa_set_interface"]
 
 _lib = None
 
@@ -120,6 +121,7 @@ def lib():
         L.fa_arc_func.argtypes = [vp] * 6
         L.fa_output_data.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
         L.fa_micro_stale_hits.argtypes = [vp, C.POINTER(C.c_int64)]
+        L.fa_set_interface.argtypes = [vp, C.c_int32, vp]
         ip = C.POINTER(C.c_int32)
         L.fa_shape_info.argtypes = [C.c_int32, ip, ip, ip]
         L.fa_shape_tables.argtypes = [C.c_int32, vp, vp, vp]
@@ -317,6 +319,12 @@ class Assembler:
         v = np.ascontiguousarray(values, dtype=np.float64)
         assert v.size == self.nip_total
         _check(lib().fa_set_history(self.h, which, _np_ptr(v)))
+
+    def set_interface(self, node_ranges):
+        """node_ranges: [(begin, end), ...] of interface nodes; afterwards assemble(..., flags | PART_INTERFACE / PART_INTERIOR)
+        issues a pass in two launches (fa_set_interface)."""
+        r = np.ascontiguousarray(np.asarray(node_ranges, dtype=np.int64).reshape(-1, 2))
+        _check(lib().fa_set_interface(self.h, r.shape[0], _np_ptr(r)))
 
     def micro_stale_hits(self):
         """Gauss points of the last assemble call in the `d > 1` branch of MicroPhaseFractureModel.cpp:772-776 (0 for every

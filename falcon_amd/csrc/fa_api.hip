@@ -60,6 +60,7 @@ struct DebugOptions {
   int  tile_sort = -1;    // FA_TILE_SORT=0|1: owned nodes of a tile in Morton order | ascending node id
   int  tile_fu = -1;      // FA_TILE_FU=0|1: 3-D elastic GET_MATRIX0 passes take f_int from the pair lanes (K u) off / on
   int  tile_lanes = -1;   // FA_TILE_LANES=0|1|2|3: pair lanes sorted over the tile | by owned node | ... without cross-tile pair lanes | ... without any shared pair lanes
+  int  tile_fset = -1;    // FA_TILE_FSET=0|1|n: GET_INT_VECTOR passes of the tile kernel on tiles of their own off / on / on with <= n elements per tile
   int  tile_budget = 0;   // FA_TILE_BUDGET=n: LDS bytes the tiles are cut for (experiments; 0: per geometry)
   int  tile_big = -1;     // FA_TILE_BIG=0|1: two 512-thread workgroups per CU | one of 1024 threads
   int  tile_cell = -1;    // FA_TILE_CELL=abc: tiles are boxes of a x b x c nodes (3-D shapes; 0: Morton cells; -1: per-shape default)
@@ -81,7 +82,7 @@ struct DebugOptions {
   static DebugOptions from_env() {
     DebugOptions o;
     auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_fu = geti("FA_TILE_FU", -1); o.tile_sort = geti("FA_TILE_SORT", -1); o.tile_split = geti("FA_TILE_SPLIT", -1); o.tile_budget = geti("FA_TILE_BUDGET", 0); o.tile_lanes = geti("FA_TILE_LANES", -1);
+    o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_fu = geti("FA_TILE_FU", -1); o.tile_sort = geti("FA_TILE_SORT", -1); o.tile_split = geti("FA_TILE_SPLIT", -1); o.tile_budget = geti("FA_TILE_BUDGET", 0); o.tile_lanes = geti("FA_TILE_LANES", -1); o.tile_fset = geti("FA_TILE_FSET", -1);
     o.emat = geti("FA_EMAT", -1); o.emat_lds = geti("FA_EMAT_LDS", 0); o.emat_lpe = geti("FA_EMAT_LPE", 0);
     o.emat_lpe_f = geti("FA_EMAT_LPE_F", 0); o.fvec = geti("FA_FVEC", -1); o.fvec_blk = geti("FA_FVEC_BLK", 0); o.fvec_cell = geti("FA_FVEC_CELL", -1); o.fvec_atomic = geti("FA_FVEC_ATOMIC", -1);
     o.persist = geti("FA_PERSIST", -1); o.tile_cell = geti("FA_TILE_CELL", -1);
@@ -352,6 +353,9 @@ struct TileDev {
   uint32_t *tpairs = nullptr, *tents = nullptr;
 };
 
+// tiles of one tile set split into the ones that own an interface node ([0]) and the others ([1]): fa_set_interface
+struct PartLists { int32_t* d[2] = { nullptr, nullptr }; int n[2] = { 0, 0 }; };
+
 struct fa_ctx {
   fa_problem prob{};
   int rank = 0, npe = 0, nip = 0, str = 0, ndofpn = 0, fam = 0, srows = 0;
@@ -388,6 +392,9 @@ struct fa_ctx {
   std::vector<double> h_tmp;
   TileDev ematK, ematF;                // element-matrix kernel (Quad4 / Triangle3)
   TileDev fvec;                        // force-vector kernel (Quad4 / Triangle3)
+  TileDev tileF;                       // tile kernel, GET_INT_VECTOR passes: a tile set of its own (no Gauss-point records: larger tiles)
+  bool parts_set = false;              // fa_set_interface has been called
+  PartLists part_rows, part_pair, part_tiles, part_fvec, part_tileF;
   DebugOptions dbg;
 };
 
@@ -403,8 +410,11 @@ extern "C" void fa_destroy(fa_ctx* c) {
                    c->d_tinfo, c->d_tnodes, c->d_telems, c->d_tconn, c->d_tpairs, c->d_tents,
                    c->ematK.tinfo, c->ematK.tnodes, c->ematK.telems, c->ematK.tconn, c->ematK.tpairs, c->ematK.tents,
                    c->ematF.tinfo, c->ematF.tnodes, c->ematF.telems, c->ematF.tconn, c->ematF.tpairs, c->ematF.tents,
-                   c->fvec.tinfo, c->fvec.tnodes, c->fvec.telems, c->fvec.tconn, c->fvec.tpairs, c->fvec.tents, c->fvec.eslot, c->fvec.nval };
+                   c->fvec.tinfo, c->fvec.tnodes, c->fvec.telems, c->fvec.tconn, c->fvec.tpairs, c->fvec.tents, c->fvec.eslot, c->fvec.nval,
+                   c->tileF.tinfo, c->tileF.tnodes, c->tileF.telems, c->tileF.tconn, c->tileF.tpairs, c->tileF.tents };
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (PartLists* pl : { &c->part_rows, &c->part_pair, &c->part_tiles, &c->part_fvec, &c->part_tileF })
+    for (int k = 0; k < 2; k++) if (pl->d[k]) (void)hipFree(pl->d[k]);
   if (c->done_ev) (void)hipEventDestroy(c->done_ev);
   delete c;
 }
@@ -934,6 +944,25 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       }
     }
   }
+  // ---- tile kernel, GET_INT_VECTOR passes: tiles of their own.  The passes run phases 0-1 only and keep no Gauss-point
+  //      records, so the LDS holds the nodal data of far larger tiles: fewer evaluations per point than on the GET_MATRIX0
+  //      tiles (Hex20 Gauss3^3: 2.9) and two 512-thread workgroups per CU whatever the geometry of the matrix pass ----
+  fa::TileSet tsT;
+  if (c->tile_path && (dbg.tile_fset >= 0 ? dbg.tile_fset != 0 : true)) {
+    const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE && p->model != FA_GRADIENT_DAMAGE;
+    fa::TileOpts o;
+    o.diag_only = true; o.order = 0; o.group = fa::tile_group(rank, c->fam);
+    o.max_el = dbg.tile_fset > 1 ? dbg.tile_fset : 512;               // (element, Gauss point) lanes: a few passes of the workgroup
+    c->tileF.ok = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
+                                  nb_ptr.data(), nb.data(), 0, fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0),
+                                  fa::kTileLds, fa::kTileBlock, false, tsT, o);
+    if (c->tileF.ok) { c->tileF.ntile = tsT.ntile; c->tileF.lds = tsT.lds_bytes; c->tileF.redundancy = tsT.point_redundancy; c->tileF.block = fa::kTileBlock; }
+    if (dbg.verbose)
+      fprintf(stderr, "[falcon_assemble] force-only tiles of the tile kernel: %s, %d tiles, %.1f owned nodes / %.1f elements per tile, LDS <= %d bytes, "
+              "Gauss-point redundancy %.3f\n", c->tileF.ok ? "ok" : "not built", tsT.ntile, tsT.ntile ? (double)nnode / tsT.ntile : 0.0,
+              tsT.ntile ? (double)tsT.telems.size() / tsT.ntile : 0.0, tsT.lds_bytes, tsT.point_redundancy);
+    if (c->tileF.ok && dbg.tiles < 0) c->tile_force_only = true;
+  }
   // ---- element-matrix kernel (Quad4, Triangle3/Gauss1): one tile set sized for the element-matrix slots of
   //      GET_MATRIX0 passes, one with f-only slots (larger tiles) for GET_INT_VECTOR passes ----
   fa::TileSet tsK, tsF;
@@ -1063,6 +1092,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     if ((s2 = upload(&d.tpairs, t.tpairs.data(), t.tpairs.size()))) return s2;
     return upload(&d.tents, t.tents.data(), std::max<size_t>(t.tents.size(), 1));
   };
+  if (c->tileF.ok && (st = upload_set(c->tileF, tsT))) return st;
   if (c->ematK.ok && (st = upload_set(c->ematK, tsK))) return st;
   if (c->ematF.ok && (st = upload_set(c->ematF, tsF))) return st;
   if (c->fvec.ok) {
@@ -1078,7 +1108,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, c->d_hist[1], nipt, 0.0);
   }
   c->max_parts = std::max(std::max(std::max(std::max(std::max(c->nwg, c->ntile2), c->ngrid_generic), c->npatch), c->ngrid_coop), c->ntile3);
-  c->max_parts = std::max(c->max_parts, std::max(std::max(c->ematK.ntile, c->ematF.ntile), c->fvec.ntile));
+  c->max_parts = std::max(c->max_parts, std::max(std::max(c->ematK.ntile, c->ematF.ntile), std::max(c->fvec.ntile, c->tileF.ntile)));
   if (p->model >= FA_MICRO_PHASE_FRACTURE && p->model <= FA_MICRO_PHASE_FRACTURE_EXTIT && p->material == FA_AMOR_PHASE) {
     HIP_TRY(hipMalloc((void**)&c->d_first_comp, sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void**)&c->d_comp_mask, sizeof(uint32_t) * std::max<int64_t>(nel, 1)));
@@ -1235,7 +1265,20 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   if (c->tile_path && (want_K || c->tile_force_only) && !(want_K && P.k2sig) && !(a->flags & (FA_FORCE_GENERIC | FA_DETERMINISTIC))) path = fa::PATH_TILES;
   // 3-D elastic tiles: f_int from the pair lanes (atomic adds to f) when K is assembled and no strain cache is asked for
   P.tile_fu = (path == fa::PATH_TILES && c->P.tile_fu && want_K && !(a->flags & FA_STORE_STRAIN)) ? 1 : 0;
-  if (P.tile_fu && P.overwrite && c->nel > 0) HIP_TRY(hipMemsetAsync(a->f_int, 0, sizeof(double) * c->ndof, st));
+  // interface / interior part of a pass (fa_set_interface): the launch runs a list of tiles instead of all of them
+  const int part = (a->flags & FA_PART_INTERFACE) ? 0 : ((a->flags & FA_PART_INTERIOR) ? 1 : -1);
+  if ((a->flags & FA_PART_INTERFACE) && (a->flags & FA_PART_INTERIOR)) return fail(FA_ERR_ARG, "FA_PART_INTERFACE and FA_PART_INTERIOR exclude each other");
+  if (part >= 0) {
+    if (!c->parts_set) return fail(FA_ERR_ARG, "FA_PART_* needs fa_set_interface first");
+    if (c->d_first_comp) return fail(FA_ERR_UNSUPPORTED, "FA_PART_*: MicroPhaseFracture* with AmorPhase needs the first compression point of the whole pass");
+    P.tile_fu = 0;                                     // f_int from the Gauss-point lanes: the K u form zeroes f for the whole mesh first
+  }
+  const bool tile_fset = path == fa::PATH_TILES && !want_K && c->tileF.ok && !emat;
+  if (tile_fset) {                                     // GET_INT_VECTOR pass of the tile kernel: its own, larger tiles
+    P.tinfo = c->tileF.tinfo; P.tnodes = c->tileF.tnodes; P.telems = c->tileF.telems; P.tconn = c->tileF.tconn;
+    P.tpairs = c->tileF.tpairs; P.tents = c->tileF.tents; P.ntile3 = c->tileF.ntile; P.tile_lds = c->tileF.lds;
+    P.tile_block = c->tileF.block; P.tile_sym = 0; P.tile_stage = 0; P.tile_split = 0;
+  }
   if (emat) {                                          // element-matrix kernel: no atomics, so it also serves FA_DETERMINISTIC
     path = (emat == &c->fvec) ? fa::PATH_FVEC : fa::PATH_EMAT;
     P.eslot = emat->eslot; P.nval = emat->nval; P.fvec_val = emat->lpe;
@@ -1252,6 +1295,7 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
       P.persistent = 1; P.st_maxn = emat->maxn; P.st_maxe = emat->maxe; P.tile_lds = emat->plds;
     }
   }
+  if (P.tile_fu && P.overwrite && c->nel > 0) HIP_TRY(hipMemsetAsync(a->f_int, 0, sizeof(double) * c->ndof, st));
   if (c->nel == 0) {
     if (P.overwrite) {
       if (want_K) HIP_TRY(hipMemsetAsync(a->K_values, 0, sizeof(double) * c->nnz, st));
@@ -1262,10 +1306,27 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
     return FA_OK;
   }
   int grid;
-  if (path == fa::PATH_PATCH) grid = c->npatch;
+  P.tile_list = nullptr;
+  if (part >= 0) {
+    const PartLists* pl = nullptr;
+    if (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) pl = &c->part_rows;
+    else if (path == fa::PATH_ROWS_PAIR) pl = &c->part_pair;
+    else if (path == fa::PATH_TILES) pl = tile_fset ? &c->part_tileF : &c->part_tiles;
+    else if (path == fa::PATH_FVEC && !emat->persistent) pl = &c->part_fvec;
+    if (!pl) return fail(FA_ERR_UNSUPPORTED, "FA_PART_*: this context runs a kernel that is not organised in node tiles (generic / cooperative / element-matrix / patch / persistent kernels)");
+    if (pl->n[part] == 0) {                            // nothing to do in this part
+      if (want_err && part == 1) HIP_TRY(hipMemsetAsync(a->err_ext, 0, sizeof(double), st));
+      HIP_TRY(hipEventRecord(c->done_ev, st));
+      return FA_OK;
+    }
+    P.tile_list = pl->d[part];
+    P.ntile = P.ntile2 = P.ntile3 = pl->n[part];
+    grid = (pl->n[part] + 7) / 8 * 8;
+  }
+  else if (path == fa::PATH_PATCH) grid = c->npatch;
   else if (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) { P.ntile = c->nwg; grid = (c->nwg + 7) / 8 * 8; }
   else if (path == fa::PATH_ROWS_PAIR) grid = (c->ntile2 + 7) / 8 * 8;
-  else if (path == fa::PATH_TILES) grid = (c->ntile3 + 7) / 8 * 8;
+  else if (path == fa::PATH_TILES) grid = ((tile_fset ? c->tileF.ntile : c->ntile3) + 7) / 8 * 8;
   else if (path == fa::PATH_EMAT || path == fa::PATH_FVEC) {
     grid = (emat->ntile + 7) / 8 * 8;
     if (emat->persistent) {                            // as many workgroups as fit the GPU at once (LDS-bound), a multiple of 8
@@ -1309,8 +1370,8 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
 #endif
   if (rc == -1000) return fail(FA_ERR_UNSUPPORTED, "kernel family not built for this shape");
   if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-  if (want_err) {
-    const int nparts = (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) ? c->nwg : (path == fa::PATH_ROWS_PAIR ? c->ntile2 : (path == fa::PATH_TILES ? c->ntile3 : ((path == fa::PATH_EMAT || path == fa::PATH_FVEC) ? emat->ntile : grid)));
+  if (want_err && part != 0) {                          // (a split pass sums its partials in the interior call: order it after the interface call)
+    const int nparts = (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) ? c->nwg : (path == fa::PATH_ROWS_PAIR ? c->ntile2 : (path == fa::PATH_TILES ? (tile_fset ? c->tileF.ntile : c->ntile3) : ((path == fa::PATH_EMAT || path == fa::PATH_FVEC) ? emat->ntile : grid)));
     hipLaunchKernelGGL(reduce_err_kernel, dim3(1), dim3(256), 0, st, err_part, nparts, a->err_ext);
     HIP_TRY(hipGetLastError());
   }
@@ -1549,5 +1610,70 @@ extern "C" fa_status fa_micro_stale_hits(const fa_ctx* c, int64_t* out) {
   unsigned long long v = 0;
   HIP_TRY(hipMemcpy(&v, c->d_stale, sizeof v, hipMemcpyDeviceToHost));
   *out = (int64_t)v;
+  return FA_OK;
+}
+
+// ---- interface-first assembly for the multi-GPU exchange ----
+// The kernels are organised in node tiles, each of which writes the rows (K rows, f_int entries) of the nodes it owns, so
+// "the interface rows first" is a launch over the tiles that own an interface node.  The lists are made here, once.
+extern "C" fa_status fa_set_interface(fa_ctx* c, int32_t nranges, const int64_t* node_ranges) {
+  if (!c || nranges < 0 || (nranges > 0 && !node_ranges)) return fail(FA_ERR_ARG, "bad argument");
+  FA_ON_DEVICE(c->prob.device);
+  std::vector<int32_t> pre((size_t)c->nnode + 1, 0);   // prefix sums of the interface marks
+  {
+    std::vector<uint8_t> mark((size_t)c->nnode, 0);
+    for (int r = 0; r < nranges; r++) {
+      const int64_t b = node_ranges[2 * r], e = node_ranges[2 * r + 1];
+      if (b < 0 || e > c->nnode || b > e) return fail(FA_ERR_ARG, "fa_set_interface: node range %d = [%lld, %lld) is outside [0, %lld]", r, (long long)b, (long long)e, (long long)c->nnode);
+      for (int64_t n = b; n < e; n++) mark[(size_t)n] = 1;
+    }
+    for (int64_t n = 0; n < c->nnode; n++) pre[(size_t)n + 1] = pre[(size_t)n] + mark[(size_t)n];
+  }
+  auto marked = [&](int64_t n) { return pre[(size_t)n + 1] != pre[(size_t)n]; };
+  auto publish = [&](PartLists& pl, const std::vector<int32_t> (&lists)[2]) -> fa_status {
+    for (int k = 0; k < 2; k++) {
+      if (pl.d[k]) { (void)hipFree(pl.d[k]); pl.d[k] = nullptr; }
+      pl.n[k] = (int)lists[k].size();
+      fa_status st = upload(&pl.d[k], lists[k].data(), lists[k].size());
+      if (st != FA_OK) return st;
+    }
+    return FA_OK;
+  };
+  // tiles that are ranges of consecutive nodes (row kernels): descriptor words 0, 1 = first node, one past the last
+  auto ranges = [&](const int32_t* d_info, int ntile, PartLists& pl) -> fa_status {
+    if (!d_info || ntile <= 0) return FA_OK;
+    std::vector<int32_t> wi((size_t)ntile * fa::kWgInfo);
+    HIP_TRY(hipMemcpy(wi.data(), d_info, wi.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> lists[2];
+    for (int t = 0; t < ntile; t++) {
+      const int32_t n0 = wi[(size_t)t * fa::kWgInfo], n1 = wi[(size_t)t * fa::kWgInfo + 1];
+      lists[(pre[(size_t)n1] != pre[(size_t)n0]) ? 0 : 1].push_back(t);
+    }
+    return publish(pl, lists);
+  };
+  // tiles with a node list, owned nodes first (tile kernel, force-vector kernel)
+  auto nodelists = [&](const int32_t* d_tinfo, const int32_t* d_tnodes, int ntile, PartLists& pl) -> fa_status {
+    if (!d_tinfo || ntile <= 0) return FA_OK;
+    std::vector<int32_t> ti((size_t)ntile * fa::kTileInfo);
+    HIP_TRY(hipMemcpy(ti.data(), d_tinfo, ti.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const size_t nn = (size_t)ti[(size_t)(ntile - 1) * fa::kTileInfo] + (size_t)ti[(size_t)(ntile - 1) * fa::kTileInfo + 1];
+    std::vector<int32_t> tn(nn);
+    HIP_TRY(hipMemcpy(tn.data(), d_tnodes, nn * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> lists[2];
+    for (int t = 0; t < ntile; t++) {
+      const int32_t* q = ti.data() + (size_t)t * fa::kTileInfo;
+      bool any = false;
+      for (int i = 0; i < q[2] && !any; i++) any = marked(tn[(size_t)q[0] + i]);
+      lists[any ? 0 : 1].push_back(t);
+    }
+    return publish(pl, lists);
+  };
+  fa_status st;
+  if (c->rows_path && (st = ranges(c->d_wginfo, c->nwg, c->part_rows))) return st;
+  if (c->pair_path && (st = ranges(c->d_wginfo2, c->ntile2, c->part_pair))) return st;
+  if (c->tile_path && (st = nodelists(c->d_tinfo, c->d_tnodes, c->ntile3, c->part_tiles))) return st;
+  if (c->fvec.ok && (st = nodelists(c->fvec.tinfo, c->fvec.tnodes, c->fvec.ntile, c->part_fvec))) return st;
+  if (c->tileF.ok && (st = nodelists(c->tileF.tinfo, c->tileF.tnodes, c->tileF.ntile, c->part_tileF))) return st;
+  c->parts_set = true;
   return FA_OK;
 }

@@ -254,8 +254,9 @@ __global__ __launch_bounds__(BLK) FA_EMAT_ATTR void assemble_emat(const Params P
 
   const int tid = threadIdx.x;
   const int per = (int)gridDim.x >> 3;                 // XCD bands: neighbouring tiles share halo nodes in one L2
-  const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-  if (tile >= P.ntile3) return;
+  const int tile0 = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (tile0 >= P.ntile3) return;
+  const int tile = P.tile_list ? P.tile_list[tile0] : tile0;   // interface / interior part of a pass (fa_set_interface)
   const int32_t* __restrict__ ti = P.tinfo + (int64_t)tile * kTileInfo;
   const int node_off = ti[0], n_all = ti[1], n_own = ti[2], elem_off = ti[3], n_el = ti[4];
   const int pair_off = ti[5], n_pairs = ti[6], ent_off = ti[7];
@@ -510,8 +511,9 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
 
   const int tid = threadIdx.x;
   const int per = (int)gridDim.x >> 3;                 // XCD bands
-  const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-  if (tile >= P.ntile3) return;
+  const int tile0 = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (tile0 >= P.ntile3) return;
+  const int tile = P.tile_list ? P.tile_list[tile0] : tile0;   // interface / interior part of a pass (fa_set_interface)
   const int32_t* __restrict__ ti = P.tinfo + (int64_t)tile * kTileInfo;
   const int node_off = ti[0], n_all = ti[1], n_own = ti[2], elem_off = ti[3], n_el = ti[4];
   const int V = P.fvec_val;                            // buffer rows per owned node (largest valence of the mesh)

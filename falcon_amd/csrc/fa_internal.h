@@ -147,6 +147,7 @@ struct Params {
   const uint32_t* tents;     // per (pair, shared element): slot | local node a << 16 | local node b << 24
   const uint32_t* eslot;     // force-vector tiles: per tile element, byte a = rank of the element at its local node a
   const uint32_t* nval;      // force-vector tiles: per tile node, incident elements (owned nodes)
+  const int32_t*  tile_list; // nullptr, or the tiles this launch runs (interface / interior part of a pass): tile = tile_list[i]
   const double*  tab;        // shape tables: N[nip][npe], dN[nip][npe][rank], w[nip]
   // ---- vectors (device) ----
   const double*  state;

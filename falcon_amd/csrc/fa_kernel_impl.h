@@ -1454,8 +1454,9 @@ __global__ __launch_bounds__(SH::BLOCK) void assemble_rows(const Params P) {
   // blockIdx % 8 is the XCD: give every XCD one contiguous band of tiles, so that the tile rows that gather the
   // same nodes meet in one L2
   const int per = (int)gridDim.x >> 3;                 // the grid is a multiple of 8
-  const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-  if (tile >= P.ntile) return;
+  const int tile0 = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (tile0 >= P.ntile) return;
+  const int tile = P.tile_list ? P.tile_list[tile0] : tile0;   // interface / interior part of a pass (fa_set_interface)
   const int32_t* __restrict__ wi = P.wginfo + (int64_t)tile * kWgInfo;
   const int n0 = wi[0], n1 = wi[1], t0 = wi[2], nlane = wi[3];
   const int64_t base = ((int64_t)(uint32_t)wi[4]) | ((int64_t)wi[5] << 32);
@@ -1611,8 +1612,9 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
     sTabL[tid] = (q < NPE * RANK) ? tD[ipt * NPE * RANK + q] : ((q < NPE * (RANK + 1)) ? tN[ipt * NPE + (q - NPE * RANK)] : ((q == NPE * (RANK + 1)) ? tW[ipt] : 0.0));
   }
   const int per = (int)gridDim.x >> 3;                 // XCD bands as in assemble_rows
-  const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-  if (tile >= P.ntile2) return;
+  const int tile0 = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (tile0 >= P.ntile2) return;
+  const int tile = P.tile_list ? P.tile_list[tile0] : tile0;   // interface / interior part of a pass (fa_set_interface)
   const int32_t* __restrict__ wi = P.wginfo2 + (int64_t)tile * kWgInfo;
   constexpr int LS = lrec_stride2(NPE);
   int32_t rec[LS];

@@ -194,6 +194,18 @@ class InterfacePlanK:
         self.ghost_rows = g_top + rows[~self.in_own]
         self.ghost_cols = g_top + cols[~self.in_own]                     # layer above: global id = interface + layer_dofs offset
 
+    def device_maps(self, device):
+        """(positions of the received entries that go into own rows, positions of the ghost entries, their places in the own K)
+        as int64 tensors on `device`, made once and kept."""
+        import torch
+        cached = getattr(self, "_dev", None)
+        if cached is None or cached[0] != device:
+            src_own = torch.from_numpy(np.nonzero(self.in_own)[0]).to(device)
+            src_ghost = torch.from_numpy(np.nonzero(~self.in_own)[0]).to(device)
+            own_idx = torch.from_numpy(np.ascontiguousarray(self.own_idx, dtype=np.int64)).to(device)
+            self._dev = cached = (device, src_own, src_ghost, own_idx)
+        return cached[1:]
+
 
 def pack_K(K, part, plan):
     return {part.rank - 1: K[:plan.send_len].contiguous() if hasattr(K, "contiguous") else K[:plan.send_len].copy()} \
@@ -207,10 +219,11 @@ def apply_K(K, part, plan, received):
         return None
     R = received[part.rank + 1]
     if hasattr(R, "cpu"):
-        import torch
-        m = torch.from_numpy(plan.in_own).to(R.device)
-        K.index_add_(0, torch.from_numpy(plan.own_idx).to(R.device), R[m])
-        return R[~m]
+        # the index maps live on the device from their first use on (round 2 uploaded 10-17 M entries per step for cfg4:
+        # more bytes over PCIe than the xGMI message they unpack)
+        src_own, src_ghost, own_idx = plan.device_maps(R.device)
+        K.index_add_(0, own_idx, R.index_select(0, src_own))
+        return R.index_select(0, src_ghost)
     np.add.at(K, plan.own_idx, R[plan.in_own])
     return R[~plan.in_own]
 
@@ -232,6 +245,69 @@ def halo_sum_K(K, part, plan, dist=None, group=None):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return apply_K(K, part, plan, recv)
+
+
+class OverlappedStep:
+    """One assembly pass of a rank with the interface exchange hidden behind the interior: the node tiles that own
+    an interface node are assembled first on a side stream (fa_set_interface, FA_PART_INTERFACE), their f_int entries and -- with a
+    plan -- K rows are packed and posted to the neighbours from that stream, and the remaining tiles (FA_PART_INTERIOR) run on
+    the caller's stream meanwhile; the received contributions are applied on the side stream, which the caller's stream joins
+    at the end.  `transport(sends_f, sends_K)` -> (recv_f, recv_K) defaults to torch.distributed point-to-point operations
+    (RCCL); the one-GPU test passes a function that plays the neighbours in-process."""
+
+    def __init__(self, asm, part, plan=None, *, capi, device=None, dist=None, group=None, transport=None):
+        import torch
+        self.asm, self.part, self.plan, self.capi = asm, part, plan, capi
+        self.dist, self.group, self.transport = dist, group, transport
+        ln, nloc = part.layer_nodes, part.nlayers + 1
+        ranges = []
+        if part.lower is not None:
+            ranges.append((0, ln))
+        if part.upper is not None:
+            ranges.append(((nloc - 1) * ln, nloc * ln))
+        asm.set_interface(ranges)
+        self.side = torch.cuda.Stream(device=device)
+        self.ghost = None
+
+    def _p2p(self, sends_f, sends_K):
+        import torch
+        import torch.distributed as tdist
+        dist = self.dist or tdist
+        part, plan = self.part, self.plan
+        ops, recv_f, recv_K = [], {}, {}
+        for peer, buf in sends_f.items():
+            recv_f[peer] = torch.empty_like(buf)
+            ops += [dist.P2POp(dist.isend, buf, peer, group=self.group), dist.P2POp(dist.irecv, recv_f[peer], peer, group=self.group)]
+        if plan is not None:
+            for peer, buf in sends_K.items():
+                ops.append(dist.P2POp(dist.isend, buf, peer, group=self.group))
+            if part.upper is not None:
+                recv_K[part.rank + 1] = torch.empty(plan.recv_len, dtype=torch.float64, device=next(iter(sends_f.values())).device)
+                ops.append(dist.P2POp(dist.irecv, recv_K[part.rank + 1], part.rank + 1, group=self.group))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        return recv_f, recv_K, reqs
+
+    def step(self, state, K, f, flags, **kw):
+        import torch
+        capi, part, plan = self.capi, self.part, self.plan
+        main = torch.cuda.current_stream(self.side.device)
+        self.side.wait_stream(main)                                   # the inputs are the caller's
+        with torch.cuda.stream(self.side):
+            self.asm.assemble(state, K, f, flags=flags | capi.PART_INTERFACE, stream=self.side.cuda_stream, **kw)
+            sends_f = pack_vector(f, part)
+            sends_K = pack_K(K, part, plan) if (plan is not None and K is not None) else {}
+            if self.transport is not None:
+                recv_f, recv_K, reqs = (*self.transport(sends_f, sends_K), [])
+            else:
+                recv_f, recv_K, reqs = self._p2p(sends_f, sends_K)
+        self.asm.assemble(state, K, f, flags=flags | capi.PART_INTERIOR, **kw)      # meanwhile, on the caller's stream
+        with torch.cuda.stream(self.side):
+            for r in reqs:
+                r.wait()                                              # RCCL: the side stream waits, not the host
+            apply_vector(f, part, recv_f)
+            self.ghost = apply_K(K, part, plan, recv_K) if (plan is not None and K is not None) else None
+        main.wait_stream(self.side)
+        return self.ghost
 
 
 def exchange_in_process(packs):

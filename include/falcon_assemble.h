@@ -98,6 +98,8 @@ enum {
   FA_OVERWRITE    = 1,  /* K = , f = over the whole pattern (== caller's zero-fill followed by +=) */
   FA_STORE_STRAIN = 2,  /* also materialise the strain_ cache (PhaseFractureModel.cpp:651,678) */
   FA_FORCE_GENERIC = 4, /* testing: use the generic atomic-scatter kernel even for a canonical pattern */
+  FA_PART_INTERFACE = 16, /* after fa_set_interface: only the tiles that own an interface node (their K rows, their f_int entries) */
+  FA_PART_INTERIOR  = 32, /* ... only the other tiles; the two calls together are one full pass (any order, any two streams) */
   FA_DETERMINISTIC = 8  /* bitwise run-to-run reproducible K/f: every entry summed in ascending element order (the ordered
                            row kernel; the force-vector kernel for GET_INT_VECTOR passes of Quad4 / Triangle3 / Hex8).  Exists for
                            Triangle3/Gauss1, Quad4 and Hex8 on the canonical node-major pattern only: on every other
@@ -198,6 +200,20 @@ fa_status fa_assemble(fa_ctx* ctx, const fa_assemble_args* args);
  * strain cache.  All calls on one GPU share the array: calls that overlap on one GPU (different streams, different
  * contexts) race on it -- serialise them. */
 fa_status fa_assemble_noalloc(fa_ctx* ctx, const fa_assemble_args* args);
+
+/* Interface-first assembly for a partitioned run (one process per GPU; the reference's counterpart is Jive's
+ * MPI decomposition, build/main.cpp:127-130,177-178, which assembles a subdomain in one piece and exchanges afterwards).
+ * node_ranges: nranges pairs [begin, end) of node indices on a partition interface (HOST array).  Afterwards a pass can
+ * be issued as two fa_assemble calls -- flags | FA_PART_INTERFACE on one stream, flags | FA_PART_INTERIOR on another --:
+ * the first computes the K rows and f_int entries of every node tile that owns an interface node (at least the interface
+ * rows; whole tiles, so usually a few node layers more), the second everything else, so that the exchange of the
+ * interface rows (RCCL over xGMI) runs while the interior is still being assembled.  Every row of K and entry of f_int is
+ * written by exactly one of the two calls; history / strain cache / errExt_ likewise (errExt_ is summed by the INTERIOR
+ * call: order it after the INTERFACE call when err_ext is requested).  Available on the node-tile kernels (Triangle3,
+ * Quad4, Hex8 and the higher-order shapes on the canonical pattern); FA_ERR_UNSUPPORTED on the generic / cooperative
+ * kernels and for MicroPhaseFracture* + AmorPhase (one first compression point per pass).  Set-up copies the tile
+ * descriptors back once: O(tiles). */
+fa_status fa_set_interface(fa_ctx* ctx, int32_t nranges, const int64_t* node_ranges);
 
 /* Same with HOST vectors (what a Jive shim holds): H2D state, assemble, D2H K/f, synchronous.
  * K_values/f_int are accumulated into or overwritten on the host according to flags. */

@@ -6,8 +6,8 @@ import numpy as np
 import pytest
 
 from falcon_amd import capi, meshgen
-from falcon_amd.distributed import (InterfacePlanK, SlabPartition, apply_K, apply_vector, exchange_in_process, pack_K,
-                                    pack_vector)
+from falcon_amd.distributed import (InterfacePlanK, OverlappedStep, SlabPartition, apply_K, apply_vector,
+                                    exchange_in_process, pack_K, pack_vector)
 from oracle import pyoracle as po
 from tests.conftest import rel_rowmax_err
 
@@ -75,3 +75,70 @@ def test_blocks_assembled_by_the_hip_path(case, dims, world):
     tol = 1e-12 * np.abs(Kd).max(axis=1, keepdims=True)
     assert np.all(np.abs(Ka - Kd) <= tol)          # additive subdomain matrices sum to the global matrix
     assert np.all(np.abs(Ko - Kd) <= tol)          # owner-complete rows + ghost block
+
+
+@pytest.mark.parametrize("case,dims", [("quad4", (150, 130)), ("hex8", (14, 12, 13)), ("quad4-force", (150, 130)), ("hex8-force", (14, 12, 13))])
+def test_interface_first_order_gives_the_same_result(case, dims):
+    """a pass issued as two launches -- the tiles that own an interface node first, on a side stream,
+    the interior on the caller's stream (fa_set_interface, FA_PART_INTERFACE / FA_PART_INTERIOR) -- writes the same K, f_int
+    and history as the one-launch pass, in overwrite and in accumulate mode; and OverlappedStep, with the middle rank of three
+    and its neighbours played in-process, ends with the same f_int / K as the sequential pack -> exchange -> apply."""
+    import torch
+    dev = torch.device("cuda", 0)
+    force = case.endswith("-force")
+    shape = capi.QUAD4_G2 if case.startswith("quad4") else capi.HEX8_G2
+    nd = len(dims) + 1
+    kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.1, keep_off_diags=False)
+    gen = meshgen.grid_quad4 if case.startswith("quad4") else meshgen.grid_hex8
+    world, r = 3, 1
+    part = SlabPartition(dims, world, r, nd)
+    lc, ln = part.local_mesh(meshgen, H)
+    lc = meshgen.distort(lc, ln, 0.1, 4)
+    st = torch.from_numpy(meshgen.smooth_state(lc, nd, amp=2e-3, noise=1e-5, l0=0.2)).to(dev)
+    a = capi.Assembler(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, lc, ln, **kw)
+    rp, ci = a.pattern()
+    z = lambda n: torch.zeros(n, dtype=torch.float64, device=dev)
+    K1 = None if force else z(a.nnz); f1 = z(a.ndof)
+    a.assemble(st, K1, f1, flags=capi.OVERWRITE)
+    torch.cuda.synchronize()
+    h1 = a.get_history(1).copy()
+    nloc = part.nlayers + 1
+    a.set_interface([(0, part.layer_nodes), ((nloc - 1) * part.layer_nodes, nloc * part.layer_nodes)])
+    for mode in (capi.OVERWRITE, capi.ACCUMULATE):
+        nanfill = lambda n: torch.full((n,), float("nan") if mode == capi.OVERWRITE else 0.0, dtype=torch.float64, device=dev)
+        K2 = None if force else nanfill(a.nnz); f2 = nanfill(a.ndof)
+        a.set_history(1, np.zeros(a.nip_total))
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        a.assemble(st, K2, f2, flags=mode | capi.PART_INTERFACE, stream=side.cuda_stream)
+        a.assemble(st, K2, f2, flags=mode | capi.PART_INTERIOR)
+        torch.cuda.synchronize()
+        fs = f1.abs().max().item()
+        assert (f2 - f1).abs().max().item() < 1e-13 * fs               # every entry written, by exactly one of the two launches
+        if not force:
+            assert rel_rowmax_err(rp, K2.cpu().numpy(), K1.cpu().numpy()) < 1e-13
+        assert np.array_equal(a.get_history(1), h1)
+    # the overlapped step against the sequential exchange, neighbours played in-process (they send what this rank would: a
+    # function of the interface entries, so the check is exact in structure and value)
+    plan = None if force else InterfacePlanK(part, rp, ci)
+    fake_f = lambda buf, k: buf * (0.5 + k)
+    def transport(sends_f, sends_K):
+        recv_f = {peer: fake_f(buf, peer) for peer, buf in sends_f.items()}
+        recv_K = {}
+        if plan is not None:
+            g = torch.Generator(device="cpu").manual_seed(3)
+            recv_K[part.rank + 1] = torch.rand(plan.recv_len, dtype=torch.float64, generator=g).to(dev)
+        return recv_f, recv_K
+    Ks = None if force else z(a.nnz); fsq = z(a.ndof)
+    a.assemble(st, Ks, fsq, flags=capi.OVERWRITE)
+    rf, rK = transport(pack_vector(fsq, part), {} if force else pack_K(Ks, part, plan))
+    apply_vector(fsq, part, rf)
+    ghost_s = None if force else apply_K(Ks, part, plan, rK)
+    Ko = None if force else z(a.nnz); fo = z(a.ndof)
+    stepper = OverlappedStep(a, part, plan, capi=capi, device=dev, transport=transport)
+    ghost_o = stepper.step(st, Ko, fo, capi.OVERWRITE)
+    torch.cuda.synchronize()
+    assert (fo - fsq).abs().max().item() < 1e-13 * fsq.abs().max().item()
+    if not force:
+        assert rel_rowmax_err(rp, Ko.cpu().numpy(), Ks.cpu().numpy()) < 1e-13
+        assert torch.equal(ghost_o, ghost_s)
