@@ -28,6 +28,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def csrc_sha16():
+    """hash of the kernel sources (scripts/make_traffic.py stores it with every traffic figure)"""
+    import hashlib
+    root = os.path.join(ROOT, "falcon_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(root)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode()); h.update(open(os.path.join(root, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes(nnz_written, ndof, nnode, rank, npe, nel, nip, phase_field):
     """every input read once, every output written once."""
     b = 8 * nnz_written + 8 * ndof + 8 * ndof + 8 * rank * nnode + 4 * npe * nel
@@ -303,13 +314,22 @@ def main():
         nnz_written = pairs * wl["written_per_pair"] if want_K else 0
         ab = algorithmic_bytes(nnz_written, asm.ndof, asm.nnode, asm.rank, asm.npe, asm.nel, asm.nip, pf)
         achieved = ab / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic of the dominant kernel from the PMC passes of scripts/r03_profiles.sh (FETCH_SIZE x 2 + WRITE_SIZE; they
+        # cannot run inside this process).  The figure is reported only if it was measured with THIS library -- the hash of
+        # the kernel sources is kept next to it -- and always with the run it comes from; otherwise null and the reason.
+        traffic, traffic_source = None, "no PMC measurement for this configuration"
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             key = f"{args.workload}:{asm.nel}:{args.mode}:{args.pattern}:{'f' if args.force_only else 'K'}"
             if args.material != "amor" or args.keep_off_diags:
                 key += f":{args.material}:{int(args.keep_off_diags)}"
-            traffic = json.load(open(tf)).get(key)
+            td = json.load(open(tf))
+            det = td.get("_detail", {}).get(key, {})
+            if key in td:
+                if det.get("csrc_sha16") == csrc_sha16():
+                    traffic, traffic_source = td[key], det.get("source")
+                else:
+                    traffic_source = f"stale: {det.get('source')} was measured with another build of the kernels"
         out = {
             "metric": "assembled elements/sec (K + f_int)" if want_K else "assembled elements/sec (f_int only)",
             "value": nel_total * args.steps / elapsed, "unit": "elements/s",
@@ -324,7 +344,7 @@ def main():
                                     if world > 1 else "single GPU",
                        "setup_seconds": round(t_setup, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "kernel_ms": kern_ms,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": ab, "bytes_per_element": ab / asm.nel},
         }
         if fonly is not None:
