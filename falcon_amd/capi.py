@@ -59,7 +59,7 @@ class AssembleArgs(C.Structure):
 EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_nip_total", "fa_ndof_per_node",
            "fa_strain_rows", "fa_uses_row_kernel", "fa_psi0", "fa_patch_stats", "fa_pattern_host", "fa_pattern_device",
            "fa_assemble", "fa_assemble_noalloc", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
-           "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum", "fa_strain_table", "fa_stress_table",
+           "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum", "fa_strain_table", "fa_stress_table", "fa_damage_table",
            "fa_pattern_device32", "fa_device", "fa_cons_create", "fa_cons_destroy", "fa_cons_set_rvalues", "fa_cons_eliminate",
            "fa_cons_eval_masters", "fa_cons_eval_slaves", "fa_residual", "fa_arc_func", "fa_output_data", "fa_micro_stale_hits", "fa_set_interface"]
 
@@ -109,6 +109,7 @@ def lib():
         L.fa_gather_sum.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
         L.fa_strain_table.argtypes = [vp, vp, vp, vp]
         L.fa_stress_table.argtypes = [vp, vp, vp, vp]
+        L.fa_damage_table.argtypes = [vp, vp, vp, vp]
         L.fa_pattern_device32.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
         L.fa_device.argtypes = [vp]; L.fa_device.restype = C.c_int32
         L.fa_cons_create.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.POINTER(vp)]
@@ -259,7 +260,8 @@ class Assembler:
         """getStrain_: table[nnode][str] and weights[nnode] (device tensors) are added to from the strain cache."""
         import torch
         assert table.is_cuda and weights.is_cuda and table.dtype == torch.float64 and weights.dtype == torch.float64
-        assert table.is_contiguous() and table.numel() == self.nnode * (self.strain_rows - (0 if self.model == LINEAR_ELASTICITY else 1))
+        # GradientDamage: str + 1 columns (e_eq last); the others: str
+        assert table.is_contiguous() and table.numel() == self.nnode * (self.strain_rows - (0 if self.model in (LINEAR_ELASTICITY, GRADIENT_DAMAGE) else 1))
         assert weights.numel() == self.nnode
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -273,6 +275,16 @@ class Assembler:
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         _check(lib().fa_stress_table(self.h, table.data_ptr(), weights.data_ptr(), stream))
+
+    def damage_table(self, table, weights, stream=None):
+        """GradientDamageModel::getDamage_ (GradientDamageModel.cpp:1184-1241): table[nnode] += sum |N| omega(newHist_),
+        weights[nnode] += sum |N|."""
+        import torch
+        assert table.is_cuda and weights.is_cuda and table.dtype == torch.float64 and weights.dtype == torch.float64
+        assert table.is_contiguous() and table.numel() == self.nnode and weights.numel() == self.nnode
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().fa_damage_table(self.h, table.data_ptr(), weights.data_ptr(), stream))
 
     def output_data(self, cols, table, weights, stream=None):
         """getOutputData_ (PhaseFractureModel.cpp:1408-1508): columns `cols` of [strain.tensor | stress.tensor]."""

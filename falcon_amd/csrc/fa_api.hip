@@ -1454,44 +1454,73 @@ __global__ void strain_table_kernel(const int32_t* __restrict__ n2e_ptr, const i
                                     int npe, int nip, int64_t nnode, double* __restrict__ table, double* __restrict__ weights) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= nnode) return;
-  double acc[6] = { 0, 0, 0, 0, 0, 0 }, w = 0.0;
+  double acc[7] = { 0, 0, 0, 0, 0, 0, 0 }, w = 0.0;    // str <= 7: GradientDamage adds the e_eq column
   for (int32_t t = n2e_ptr[n]; t < n2e_ptr[n + 1]; t++) {
     const int32_t ent = n2e_ent[t];
     const int64_t e = ent / npe; const int la = ent - (int32_t)e * npe;
-    double el[6] = { 0, 0, 0, 0, 0, 0 }, ew = 0.0;
+    double el[7] = { 0, 0, 0, 0, 0, 0, 0 }, ew = 0.0;
     for (int ip = 0; ip < nip; ip++) {
       const double N = tabN[ip * npe + la];
       const double* sp = strain + (e * nip + ip) * srows;
-      for (int c = 0; c < 6; c++) if (c < str) el[c] += N * sp[c];
+      for (int c = 0; c < 7; c++) if (c < str) el[c] += N * sp[c];
       ew += N;
     }
-    for (int c = 0; c < 6; c++) acc[c] += el[c];
+    for (int c = 0; c < 7; c++) acc[c] += el[c];
     w += ew;
   }
-  for (int c = 0; c < 6; c++) if (c < str) table[n * str + c] += acc[c];
+  for (int c = 0; c < 7; c++) if (c < str) table[n * str + c] += acc[c];
   weights[n] += w;
 }
 
 extern "C" fa_status fa_strain_table(fa_ctx* c, double* table, double* weights, void* stream) {
   if (!c || !table || !weights) return fail(FA_ERR_ARG, "null argument");
   if (!c->d_strain) return fail(FA_ERR_ARG, "no strain cache: assemble with FA_STORE_STRAIN first");
+  // GradientDamageModel::getStrain_ (GradientDamageModel.cpp:1071-1177): strCount + 1 columns, the last one the nonlocal
+  // equivalent strain "e_eq" (:1135, :1161); its column switch (:1097-1131) has no case 4, so in 2-D the reference throws
+  int ncol = c->str;
+  if (c->prob.model == FA_GRADIENT_DAMAGE) {
+    if (c->str != 1 && c->str != 3 && c->str != 6)
+      return fail(FA_ERR_UNSUPPORTED, "unexpected number of strain components: %d (GradientDamageModel::getStrain_ throws this in 2-D, GradientDamageModel.cpp:1124-1130)", c->str);
+    ncol = c->str + 1;
+  }
   FA_ON_DEVICE(c->prob.device);
   if (c->nnode == 0) return FA_OK;
   hipLaunchKernelGGL(strain_table_kernel, dim3((unsigned)((c->nnode + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     c->d_n2e_ptr, c->d_n2e_ent, c->d_tab, c->d_strain, c->srows, c->str, c->npe, c->nip, c->nnode, table, weights);
+                     c->d_n2e_ptr, c->d_n2e_ent, c->d_tab, c->d_strain, c->srows, ncol, c->npe, c->nip, c->nnode, table, weights);
   HIP_TRY(hipGetLastError());
   return FA_OK;
 }
 
+// GradientDamageModel's getStress_ (0) / getDamage_ (1) / getOutputData_ point values (2): fa_tile_impl.h, gd_table_kernel
+static fa_status gd_table(fa_ctx* c, fa::Params& P, int mode, double* out, double* weights, void* stream) {
+  P.hist_pre = c->d_hist[0]; P.hist_new = c->d_hist[1];
+  const int ps = (c->prob.state == FA_PLANE_STRESS) ? 1 : 0;
+  const int rc = (c->rank == 2) ? fa::launch_gd_table_2d(P, c->npe, c->nip, ps, mode, out, weights, stream)
+                                : fa::launch_gd_table_3d(P, c->npe, c->nip, ps, mode, out, weights, stream);
+  if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  HIP_TRY(hipEventRecord(c->done_ev, (hipStream_t)stream));   // modes 0 and 2 rewrite newHist_: the history getters wait for it
+  return FA_OK;
+}
+
+// getDamage_ (GradientDamageModel.cpp:1184-1241)
+extern "C" fa_status fa_damage_table(fa_ctx* c, double* table, double* weights, void* stream) {
+  if (!c || !table || !weights) return fail(FA_ERR_ARG, "null argument");
+  if (c->prob.model != FA_GRADIENT_DAMAGE) return fail(FA_ERR_UNSUPPORTED, "fa_damage_table: getDamage_ belongs to GradientDamage");
+  FA_ON_DEVICE(c->prob.device);
+  if (c->nnode == 0) return FA_OK;
+  fa::Params P = c->P;
+  return gd_table(c, P, 1, table, weights, stream);
+}
+
 extern "C" fa_status fa_stress_table(fa_ctx* c, double* table, double* weights, void* stream) {
   if (!c || !table || !weights) return fail(FA_ERR_ARG, "null argument");
-  if (c->prob.model == FA_GRADIENT_DAMAGE) return fail(FA_ERR_UNSUPPORTED, "fa_stress_table: not provided for GradientDamage (its strain cache holds the nonlocal equivalent strain, not a degradation)");
   if (!c->d_strain) return fail(FA_ERR_ARG, "no strain cache: assemble with FA_STORE_STRAIN first");
   FA_ON_DEVICE(c->prob.device);
   if (c->nnode == 0) return FA_OK;
   fa::Params P = c->P;
   P.strain = c->d_strain;
   const int ps = (c->prob.state == FA_PLANE_STRESS) ? 1 : 0;
+  if (c->prob.model == FA_GRADIENT_DAMAGE) return gd_table(c, P, 0, table, weights, stream);
   const int rc = (c->rank == 2) ? fa::launch_stress_table_2d(P, c->npe, c->nip, ps, table, weights, stream)
                                 : fa::launch_stress_table_3d(P, c->npe, c->nip, ps, table, weights, stream);
   if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -1512,11 +1541,23 @@ __global__ void output_split_filter_kernel(int64_t nnode, int str, int ncols, co
   weights[n] += wtmp[n];
 }
 
-// getOutputData_ (PhaseFractureModel.cpp:1408-1508): strain.tensor and stress.tensor columns, filtered
+// table[n][j] += all[n][cols[j]] for point values stored interleaved
+__global__ void output_filter_kernel(int64_t nnode, int ntmp, int ncols, const int32_t* __restrict__ cols,
+                                     const double* __restrict__ all, const double* __restrict__ wtmp,
+                                     double* __restrict__ table, double* __restrict__ weights) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nnode) return;
+  for (int j = 0; j < ncols; j++) table[n * ncols + j] += all[n * ntmp + cols[j]];
+  weights[n] += wtmp[n];
+}
+
+// getOutputData_ (PhaseFractureModel.cpp:1408-1508): strain.tensor and stress.tensor columns, filtered;
+// GradientDamageModel.cpp:1254-1365: [strain.tensor | stress.tensor | damage]
 extern "C" fa_status fa_output_data(fa_ctx* c, int32_t ncols, const int32_t* cols, double* table, double* weights, void* stream) {
   if (!c || !table || !weights || ncols < 0 || (ncols > 0 && !cols)) return fail(FA_ERR_ARG, "bad argument");
   if (!c->d_strain) return fail(FA_ERR_ARG, "no strain cache: assemble with FA_STORE_STRAIN first");
-  const int str = c->str, ntmp = 2 * str;
+  const bool gd = c->prob.model == FA_GRADIENT_DAMAGE;
+  const int str = c->str, ntmp = 2 * str + (gd ? 1 : 0);   // GradientDamage announces "damage" after the two tensors (:1270-1273)
   if (ncols > ntmp) return fail(FA_ERR_ARG, "fa_output_data: %d columns requested, the point values have %d", ncols, ntmp);
   for (int j = 0; j < ncols; j++)
     if (cols[j] < 0 || cols[j] >= ntmp) return fail(FA_ERR_ARG, "fa_output_data: column %d out of range [0, %d)", cols[j], ntmp);
@@ -1532,6 +1573,18 @@ extern "C" fa_status fa_output_data(fa_ctx* c, int32_t ncols, const int32_t* col
   int32_t* dcols = (int32_t*)(w2 + nn);
   HIP_TRY(hipMemsetAsync(c->d_out_tmp, 0, sizeof(double) * nn * (ntmp + 2), st));
   if (ncols > 0) HIP_TRY(hipMemcpyAsync(dcols, cols, sizeof(int32_t) * ncols, hipMemcpyHostToDevice, st));
+  if (gd) {                                            // one kernel writes all 2 str + 1 point values, interleaved
+    fa::Params P = c->P;
+    P.strain = c->d_strain;
+    double* tall = c->d_out_tmp; double* wg = tall + nn * ntmp;   // dcols = wg + nn: the column ids sit behind both
+    fa_status grc = gd_table(c, P, 2, tall, wg, stream);
+    if (grc != FA_OK) return grc;
+    hipLaunchKernelGGL(output_filter_kernel, dim3((unsigned)((c->nnode + 255) / 256)), dim3(256), 0, st, c->nnode, ntmp, ncols,
+                       dcols, tall, wg, table, weights);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return FA_OK;
+  }
   fa_status rc = fa_strain_table(c, tstrain, w1, stream);
   if (rc != FA_OK) return rc;
   if ((rc = fa_stress_table(c, tstress, w2, stream)) != FA_OK) return rc;

@@ -207,6 +207,9 @@ int launch_fvec_tri3_g1 (const Params&, int fam, int grid, void* stream);
 int launch_fvec_hex8_g2 (const Params&, int fam, int grid, void* stream);
 
 // getStress_ table kernels, one per space dimension (fa_kernels_quad4.hip / fa_kernels_hex8.hip)
+// GradientDamageModel's tables: mode 0 getStress_, 1 getDamage_, 2 getOutputData_ point values (fa_tile_impl.h)
+int launch_gd_table_2d(const Params&, int npe, int nip, int plane_stress, int mode, double* out, double* weights, void* stream);
+int launch_gd_table_3d(const Params&, int npe, int nip, int plane_stress, int mode, double* out, double* weights, void* stream);
 int launch_stress_table_2d(const Params&, int npe, int nip, int plane_stress, double* table, double* weights, void* stream);
 int launch_stress_table_3d(const Params&, int npe, int nip, int plane_stress, double* table, double* weights, void* stream);
 

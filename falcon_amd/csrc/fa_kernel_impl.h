@@ -471,6 +471,63 @@ __device__ __forceinline__ void Bt_vec(const double (&ga)[RANK], const double (&
   }
 }
 
+// damageEvolution_ / getdOmegadKappa (DamageMaterial.cpp:712-855, laws :1044-1633): omega(kappa) and its derivative
+__device__ __forceinline__ void damage_law(const Params& P, const double kappa, double& omega, double& domega) {
+  omega = 0.0; domega = 0.0;
+  const double Ki = P.kI, Kc = P.kC, K = kappa;
+  if (P.soft == 0) {
+    if (K >= Ki) omega = 1.0 - Ki / K;
+    domega = (K < Ki) ? 0.0 : Ki / (K * K);
+  } else if (P.soft == 1) {
+    if (K >= Ki) { omega = K > Kc ? 1.0 : Kc * (K - Ki) / (K * (Kc - Ki)); if (omega == 1.0) omega = 0.999; }
+    domega = (K < Kc) ? (Ki * Kc) / ((Kc - Ki) * K * K) : 0.0;
+  } else if (P.soft == 2) {
+    if (K >= Ki) omega = K > Kc ? 0.999 : (K - Ki) / (Kc - Ki);
+    domega = (K < Kc) ? 1.0 / (Kc - Ki) : 0.0;
+  } else if (P.soft == 3) {
+    const double ex = exp(-P.sB * (K - Ki));
+    if (K >= Ki) omega = 1.0 - (Ki / K) * (1.0 - P.sA + P.sA * ex);
+    const double a = Ki / (K * K), b = a * K, c = P.sA * ex;
+    domega = a * (1.0 - P.sA + c) + P.sB * b * c;
+  } else if (P.soft == 4) {
+    const double ex = exp((Ki - K) / (Kc - Ki));
+    if (K >= Ki) omega = 1.0 - (Ki / K) * ex;
+    const double d = Ki / (K * K);
+    domega = d * ex + d * K * ex / (Kc - Ki);
+  } else if (P.soft == 5) {                       // power (:1389-1413, :1446-1472), Kcc = Kc
+    const double a = Ki / K, b = 1.0 / (Kc - Ki), c = (Kc - K) * b;
+    if (K >= Ki) {
+      const double omegac = 1.0 - pow(Ki / Kc, P.sB) * pow((Kc - Kc) / (Kc - Ki), P.sA);
+      omega = (K > Kc) ? omegac : 1.0 - pow(a, P.sB) * pow((Kc - K) / (Kc - Ki), P.sA);
+    }
+    domega = (K > Kc) ? 0.0 : pow(a, P.sB - 1.0) * pow(c, P.sA - 1.0) * ((a / K) * P.sB * c + a * P.sA * b);
+  } else if (P.soft == 6) {                       // hyperbolic (:1350-1380), sA = b; isTiny as in the checker
+    const double q = 1.0 + P.sA * (K - Ki);
+    if (K >= Ki) { omega = 1.0 - 1.0 / q; if (fabs(1.0 - omega) < 2.2250738585072014e-308) omega = 0.999; }
+    domega = P.sA / q / q;
+  } else if (P.soft == 7) {                       // exponential2Reg: not in the overloads GradientDamage reaches
+  } else if (P.soft == 8) {                       // expoEnergy (:1495-1523), sA = s
+    if (K >= Ki) {
+      const double t = (K - Ki) / Kc, tem1 = pow(t, P.sA), tem2 = pow(t, P.sA - 1.0);
+      omega = 1.0 - exp(-tem1);
+      domega = exp(-tem1) * tem2 * P.sA / Kc;
+    }
+  } else if (P.soft == 9) {                       // polynomial (:1530-1574); d from the un-normalised a, verbatim
+    if (K >= Ki) {
+      const double an = (K - Ki) / (Kc - Ki);
+      omega = 1.0 - (Ki / K) * (1.0 + (an * an) * (2.0 * an - 3.0));
+      const double a = Ki - K, b = Kc - Ki, c = a / b, d = 1.0 + (a * a) * (2.0 * a - 3.0);
+      domega = -Ki / (K * K) * (2.0 * K * (c / b * (2.0 * c - 3.0) + (c * c) / b) - d);
+    }
+  } else {                                        // multilinear (:1581-1633), sA = kappaP
+    const double Kp = P.sA;
+    if (K >= Ki) {
+      if (K > Kp) { omega = 1.0 - Ki / K; domega = Ki / (K * K); }
+      else { omega = (K < Kp) ? 0.0 : (K > Kc ? 0.999 : (K - Kp) / (Kc - Kp)); domega = (K < Kc) ? 1.0 / (Kc - Kp) : 0.0; }
+    }
+  }
+}
+
 // von Mises equivalent strain (DamageMaterial.cpp:609-617, :667-684; VonMisesStrain.cpp:49-116; J2 and its gradient with
 // respect to the tensor components, Invariants.cpp:111-118, :188-202).  3-D only.
 template <int S>
@@ -703,61 +760,8 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
         if (fl == 0.0)     { kappa = kappa0; load = load0; }
         else if (fl > 0.0) { kappa = pf; load = (kappa < P.kI) ? 0 : 1; }
         else               { kappa = kappa0; load = 0; }
-        double omega = 0.0, domega = 0.0;                 // damageEvolution_ / getdOmegadKappa (:712-855, :1044-1260)
-        {
-          const double Ki = P.kI, Kc = P.kC, K = kappa;
-          if (P.soft == 0) {
-            if (K >= Ki) omega = 1.0 - Ki / K;
-            domega = (K < Ki) ? 0.0 : Ki / (K * K);
-          } else if (P.soft == 1) {
-            if (K >= Ki) { omega = K > Kc ? 1.0 : Kc * (K - Ki) / (K * (Kc - Ki)); if (omega == 1.0) omega = 0.999; }
-            domega = (K < Kc) ? (Ki * Kc) / ((Kc - Ki) * K * K) : 0.0;
-          } else if (P.soft == 2) {
-            if (K >= Ki) omega = K > Kc ? 0.999 : (K - Ki) / (Kc - Ki);
-            domega = (K < Kc) ? 1.0 / (Kc - Ki) : 0.0;
-          } else if (P.soft == 3) {
-            const double ex = exp(-P.sB * (K - Ki));
-            if (K >= Ki) omega = 1.0 - (Ki / K) * (1.0 - P.sA + P.sA * ex);
-            const double a = Ki / (K * K), b = a * K, c = P.sA * ex;
-            domega = a * (1.0 - P.sA + c) + P.sB * b * c;
-          } else if (P.soft == 4) {
-            const double ex = exp((Ki - K) / (Kc - Ki));
-            if (K >= Ki) omega = 1.0 - (Ki / K) * ex;
-            const double d = Ki / (K * K);
-            domega = d * ex + d * K * ex / (Kc - Ki);
-          } else if (P.soft == 5) {                       // power (:1389-1413, :1446-1472), Kcc = Kc
-            const double a = Ki / K, b = 1.0 / (Kc - Ki), c = (Kc - K) * b;
-            if (K >= Ki) {
-              const double omegac = 1.0 - pow(Ki / Kc, P.sB) * pow((Kc - Kc) / (Kc - Ki), P.sA);
-              omega = (K > Kc) ? omegac : 1.0 - pow(a, P.sB) * pow((Kc - K) / (Kc - Ki), P.sA);
-            }
-            domega = (K > Kc) ? 0.0 : pow(a, P.sB - 1.0) * pow(c, P.sA - 1.0) * ((a / K) * P.sB * c + a * P.sA * b);
-          } else if (P.soft == 6) {                       // hyperbolic (:1350-1380), sA = b; isTiny as in the checker
-            const double q = 1.0 + P.sA * (K - Ki);
-            if (K >= Ki) { omega = 1.0 - 1.0 / q; if (fabs(1.0 - omega) < 2.2250738585072014e-308) omega = 0.999; }
-            domega = P.sA / q / q;
-          } else if (P.soft == 7) {                       // exponential2Reg: not in the overloads GradientDamage reaches
-          } else if (P.soft == 8) {                       // expoEnergy (:1495-1523), sA = s
-            if (K >= Ki) {
-              const double t = (K - Ki) / Kc, tem1 = pow(t, P.sA), tem2 = pow(t, P.sA - 1.0);
-              omega = 1.0 - exp(-tem1);
-              domega = exp(-tem1) * tem2 * P.sA / Kc;
-            }
-          } else if (P.soft == 9) {                       // polynomial (:1530-1574); d from the un-normalised a, verbatim
-            if (K >= Ki) {
-              const double an = (K - Ki) / (Kc - Ki);
-              omega = 1.0 - (Ki / K) * (1.0 + (an * an) * (2.0 * an - 3.0));
-              const double a = Ki - K, b = Kc - Ki, c = a / b, d = 1.0 + (a * a) * (2.0 * a - 3.0);
-              domega = -Ki / (K * K) * (2.0 * K * (c / b * (2.0 * c - 3.0) + (c * c) / b) - d);
-            }
-          } else {                                        // multilinear (:1581-1633), sA = kappaP
-            const double Kp = P.sA;
-            if (K >= Ki) {
-              if (K > Kp) { omega = 1.0 - Ki / K; domega = Ki / (K * K); }
-              else { omega = (K < Kp) ? 0.0 : (K > Kc ? 0.999 : (K - Kp) / (Kc - Kp)); domega = (K < Kc) ? 1.0 / (Kc - Kp) : 0.0; }
-            }
-          }
-        }
+        double omega, domega;
+        damage_law(P, kappa, omega, domega);
         const double s1 = 1.0 - omega;
         r.d0 = s1 * P.hd0; r.d1 = s1 * P.hd1; r.d3 = s1 * P.hd3;      // stiff = (1 - omega) elasticMod_ (:421)
 #pragma unroll

@@ -14,6 +14,9 @@ int launch_arc_func_3d(const Params& P, int npe, int nip, const double* state0, 
   return launch_arc_func_rank<3>(P, npe, nip, state0, jac10, part, stream);
 }
 
+int launch_gd_table_3d(const Params& P, int npe, int nip, int plane_stress, int mode, double* out, double* weights, void* stream) {
+  return launch_gd_table_rank<3>(P, npe, nip, plane_stress, mode, out, weights, stream);
+}
 int launch_stress_table_3d(const Params& P, int npe, int nip, int plane_stress, double* table, double* weights, void* stream) {
   return launch_stress_table_rank<3>(P, npe, nip, plane_stress, table, weights, stream);
 }

@@ -978,6 +978,141 @@ static int launch_stress_table_rank(const Params& P, int npe, int nip, int plane
   return (int)hipGetLastError();
 }
 
+// ---- GradientDamageModel's tables (GradientDamageModel.cpp:956-1365) ----
+// DamageMaterial::update (DamageMaterial.cpp:356-437) at one Gauss point from the cached strain: `local` = the caller
+// hands the material a strain of stress size, so the equivalent strain is computed from the strain (:370-373,
+// getOutputData_), otherwise it is the cached nonlocal one in row STR (:374-377, getStress_).  sig: all STR components
+// (2-D: xx, yy, zz, xy; the cached zz strain is 0).  hnew: newHist_ as :434-435 leave it (kappa, negative = loading).
+template <int RANK>
+__device__ __forceinline__ void gd_point_update(const Params& P, const double* __restrict__ sc, const double H0, const bool local,
+                                                const int plane_stress, double* sig, double& hnew) {
+  constexpr int S = (RANK == 2) ? 3 : 6, STR = (RANK == 2) ? 4 : 6;
+  double eps[S], e0v[S], psi2 = 0.0;
+  if constexpr (RANK == 2) { eps[0] = sc[0]; eps[1] = sc[1]; eps[2] = sc[3]; }
+  else {
+#pragma unroll
+    for (int c = 0; c < S; c++) eps[c] = sc[c];
+  }
+#pragma unroll
+  for (int i = 0; i < S; i++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < S; j++) {
+      const double dij = (i < RANK && j < RANK) ? ((i == j) ? P.hd0 : P.hd1) : ((i == j) ? P.hd3 : 0.0);
+      acc += dij * eps[j];
+    }
+    e0v[i] = acc; psi2 += acc * eps[i];
+  }
+  double eq = sc[STR];
+  if (local) {
+    double deq[S];
+    eq = 0.5 * psi2;                                     // getEquiStrain (:602-652)
+    if (P.eqv == 1) mazars_strain<RANK, S>(P, eps, eq, deq);
+    else if (P.eqv == 2) vonmises_strain<S>(P, eps, eq, deq);
+  }
+  const double kappa0 = fabs(H0);
+  const int load0 = (H0 < 0.0) ? 1 : 0;
+  const double fl = eq - kappa0;
+  double kappa; int load;
+  if (fl == 0.0)     { kappa = kappa0; load = load0; }
+  else if (fl > 0.0) { kappa = eq; load = (kappa < P.kI) ? 0 : 1; }
+  else               { kappa = kappa0; load = 0; }
+  double omega, domega;
+  damage_law(P, kappa, omega, domega);
+  const double s1 = 1.0 - omega;
+  if constexpr (RANK == 2) {
+    sig[0] = s1 * e0v[0]; sig[1] = s1 * e0v[1]; sig[3] = s1 * e0v[2];
+    sig[2] = plane_stress ? 0.0 : (s1 * P.hd1) * eps[0] + (s1 * P.hd1) * eps[1];
+  } else {
+#pragma unroll
+    for (int c = 0; c < S; c++) sig[c] = s1 * e0v[c];
+  }
+  hnew = load ? -kappa : kappa;
+}
+
+// One lane per node over its incident elements, per element first, like the reference's element loops.  mode 0:
+// getStress_ (:956-1063), NC = STR columns; mode 1: getDamage_ (:1184-1241), one column, omega of newHist_ weighed with
+// |N| (values and weights, :1233-1234); mode 2: getOutputData_ (:1254-1365), the 2 STR + 1 point values
+// [strain.tensor | stress.tensor (local update) | damage (giveOmega() before the loop, :1316)].  out is ADDED to.
+template <int RANK, int MODE>
+__global__ void gd_table_kernel(const Params P, int npe, int nip, int plane_stress, double* __restrict__ out,
+                                double* __restrict__ weights) {
+  constexpr int STR = (RANK == 2) ? 4 : 6;
+  constexpr int NC = (MODE == 0) ? STR : (MODE == 1) ? 1 : 2 * STR + 1;
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= P.nnode) return;
+  double acc[NC], w = 0.0;
+#pragma unroll
+  for (int c = 0; c < NC; c++) acc[c] = 0.0;
+  for (int32_t t = P.n2e_ptr[n]; t < P.n2e_ptr[n + 1]; t++) {
+    const int32_t ent = P.n2e_ent[t];
+    const int64_t e = ent / npe; const int la = ent - (int32_t)e * npe;
+    double el[NC], ew = 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; c++) el[c] = 0.0;
+#pragma unroll 1
+    for (int ip = 0; ip < nip; ip++) {
+      const int64_t ipoint = e * nip + ip;
+      double N = P.tab[ip * npe + la];
+      if constexpr (MODE == 1) {
+        N = fabs(N);
+        double omega, domega;
+        damage_law(P, fabs(P.hist_new[ipoint]), omega, domega);       // giveOmega (DamageMaterial.cpp:533-545)
+        el[0] += N * omega;
+      } else {
+        const double* sc = P.strain + ipoint * (STR + 1);
+        double sig[STR], hnew;
+        gd_point_update<RANK>(P, sc, P.hist_pre[ipoint], MODE == 2, plane_stress, sig, hnew);
+        if constexpr (MODE == 0) {
+#pragma unroll
+          for (int c = 0; c < STR; c++) el[c] += N * sig[c];
+        } else {
+          double omega, domega;
+          damage_law(P, fabs(P.hist_new[ipoint]), omega, domega);
+#pragma unroll
+          for (int c = 0; c < STR; c++) { el[c] += N * sc[c]; el[STR + c] += N * sig[c]; }
+          el[2 * STR] += N * omega;
+        }
+      }
+      ew += N;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] += el[c];
+    w += ew;
+  }
+#pragma unroll
+  for (int c = 0; c < NC; c++) out[n * NC + c] += acc[c];
+  weights[n] += w;
+}
+
+// the history side of the same update (DamageMaterial.cpp:434-435): one lane per Gauss point, after the table kernel
+template <int RANK>
+__global__ void gd_hist_update_kernel(const Params P, int64_t npoint, int local, int plane_stress) {
+  constexpr int STR = (RANK == 2) ? 4 : 6;
+  const int64_t ipoint = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ipoint >= npoint) return;
+  double sig[STR], hnew;
+  gd_point_update<RANK>(P, P.strain + ipoint * (STR + 1), P.hist_pre[ipoint], local != 0, plane_stress, sig, hnew);
+  P.hist_new[ipoint] = hnew;
+}
+
+template <int RANK>
+static int launch_gd_table_rank(const Params& P, int npe, int nip, int plane_stress, int mode, double* out, double* weights,
+                                void* stream) {
+  const dim3 grid((unsigned)((P.nnode + 127) / 128)), blk(128);
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0)      hipLaunchKernelGGL((gd_table_kernel<RANK, 0>), grid, blk, 0, st, P, npe, nip, plane_stress, out, weights);
+  else if (mode == 1) hipLaunchKernelGGL((gd_table_kernel<RANK, 1>), grid, blk, 0, st, P, npe, nip, plane_stress, out, weights);
+  else                hipLaunchKernelGGL((gd_table_kernel<RANK, 2>), grid, blk, 0, st, P, npe, nip, plane_stress, out, weights);
+  int rc = (int)hipGetLastError();
+  if (rc != 0 || mode == 1) return rc;
+  const int64_t npoint = P.nel * nip;
+  if (npoint > 0)
+    hipLaunchKernelGGL(gd_hist_update_kernel<RANK>, dim3((unsigned)((npoint + 255) / 256)), dim3(256), 0, st, P, npoint,
+                       mode == 2 ? 1 : 0, plane_stress);
+  return (int)hipGetLastError();
+}
+
 // getArcFunc_ (PhaseFractureModel.cpp:844-1063): one lane per node over its incident elements (ascending, like the
 // reference's element loop reaches the node); per Gauss point the strain, the current and old degradation, the material
 // update with the current one (Psi = givePsi(), sigma+ = giveDerivPsi(), no history maximum: :1033-1038), then

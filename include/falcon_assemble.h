@@ -248,15 +248,33 @@ fa_status fa_get_strain_cache(const fa_ctx* ctx, double* host_out);
 fa_status fa_strain_table(fa_ctx* ctx, double* table, double* weights, void* stream);
 /* getStress_ (PhaseFractureModel.cpp:1165-1271; LinearElasticityModel's is the same loop with Hooke): like
  * fa_strain_table, but every Gauss point's stress comes from the material update with the cached strain and the cached
- * degradation (`update(stressIp, stiff, strainIp, gphiEx, ipoint)`), all str components (2-D: xx, yy, zz, xy). */
+ * degradation (`update(stressIp, stiff, strainIp, gphiEx, ipoint)`), all str components (2-D: xx, yy, zz, xy).
+ *
+ * FA_GRADIENT_DAMAGE (GradientDamageModel.cpp:884-1241, GET_TABLE "strain" / "stress" / "damage"):
+ *  - fa_strain_table follows GradientDamageModel::getStrain_ (:1071-1177): str + 1 columns, the last one the nonlocal
+ *    equivalent strain "e_eq" (table: [nnode][7] in 3-D).  The reference's column switch has no case for str = 4, so its
+ *    2-D call throws "unexpected number of strain components: 4" (:1124-1130); fa_strain_table returns
+ *    FA_ERR_UNSUPPORTED with that message.
+ *  - fa_stress_table follows getStress_ (:956-1063): `material_->update(stressIp, stiff, strain_(ALL,ipoint), ipoint)`
+ *    with all str + 1 cached rows, i.e. DamageMaterial's nonlocal branch (DamageMaterial.cpp:374-377): kappa from the
+ *    cached nonlocal strain and preHist_, stress = (1 - omega) D eps.  Like the reference's update it REWRITES newHist_
+ *    (:434-435) -- the values the last fa_assemble wrote, unless fa_commit / fa_set_history came in between.
+ *  - fa_damage_table follows getDamage_ (:1184-1241): one column "hist" = omega(newHist_ kappa) (giveOmega,
+ *    DamageMaterial.cpp:533-545), values and weights both weighed with |N_node(ip)| (:1233-1234).  table: [nnode]. */
 fa_status fa_stress_table(fa_ctx* ctx, double* table, double* weights, void* stream);
+fa_status fa_damage_table(fa_ctx* ctx, double* table, double* weights, void* stream);
 
 /* getOutputData_ (PhaseFractureModel.cpp:1408-1508): per Gauss point the values [strain.tensor | stress.tensor]
  * (2 str entries: 8 in 2-D, 12 in 3-D; TbFiller's announce order, :1424-1425), the stress from the material update with
  * the cached strain and degradation (:1482-1486); the columns cols[0..ncols) of them (TbFiller's filter, i2table,
  * :1438-1439,:1492; host array) are extrapolated with the shape functions and ADDED to table (device, [nnode][ncols]),
  * the shape-function sums to weights (device, [nnode]) -- once per element, as :1497-1506 do.  Needs a strain cache
- * (FA_STORE_STRAIN).  The context keeps a scratch of nnode * (2 str + 2) doubles after the first call. */
+ * (FA_STORE_STRAIN).  The context keeps a scratch of nnode * (2 str + 2) doubles after the first call.
+ * FA_GRADIENT_DAMAGE (GradientDamageModel.cpp:1254-1365): the point values are [strain.tensor | stress.tensor | damage]
+ * (2 str + 1 entries, :1270-1273).  damage = giveOmega() of newHist_ as it is BEFORE the call (:1316); the stress comes
+ * from `update(stress, stiff, strain, ipoint)` with a strain of stress size (:1340-1343), which sends DamageMaterial down
+ * its LOCAL branch (equivalent strain computed from the strain, DamageMaterial.cpp:370-373) and rewrites newHist_ with
+ * that outcome (:434-435) -- reproduced, so a following fa_damage_table / fa_commit sees what the reference's would. */
 fa_status fa_output_data(fa_ctx* ctx, int32_t ncols, const int32_t* cols, double* table, double* weights, void* stream);
 
 /* getArcFunc_ (PhaseFractureModel.cpp:844-1063; ArclenActions::GET_ARC_FUNC of the dissipation-based

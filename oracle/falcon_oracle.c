@@ -1173,6 +1173,170 @@ static int assemble_gd(const fo_config* cfg, const double* coords, const int32_t
   return 0;
 }
 
+/* ---- GradientDamageModel's tables (GET_TABLE, GradientDamageModel.cpp:884-948) ---- */
+
+/* DamageMaterial::update (DamageMaterial.cpp:356-437) at one point, the secant matrix left out: `m_entries` is the size
+ * of the strain vector the caller hands in.  strCount + 1 entries: the last one is the nonlocal equivalent strain
+ * (:374-377); strCount entries: "local damage models", the equivalent strain is computed from the strain (:370-373).
+ * hist_pre / hist_new as in assemble_gd (kappa, negative when the loading flag is set); newHist_ is rewritten (:434-435). */
+static void damage_update_point(const fo_config* cfg, int rank, const double* stiff0, const double* strain, int m_entries,
+                                double hist_pre, double* stress, double* hist_new) {
+  const int n = STRAIN_COUNTS[rank];
+  double equiStrain;
+  if (n == m_entries) {
+    double d0e[MAXSTR];
+    matvec(n, stiff0, strain, d0e);
+    equiStrain = (cfg->eqv_strain == FO_EQV_MAZARS) ? mazars_eq(rank, strain)
+               : (cfg->eqv_strain == FO_EQV_VONMISES) ? vonmises_eq(cfg, rank, strain)
+                                                      : 0.5 * dotn(n, strain, d0e);       /* getEquiStrain (:602-652) */
+  } else equiStrain = strain[n];
+  const double kappa0 = fabs(hist_pre);
+  const int load0 = hist_pre < 0.0;
+  const double f = equiStrain - kappa0;
+  double kappa; int load;
+  if (f == 0.0) { kappa = kappa0; load = load0; }
+  else if (f > 0.0) { kappa = equiStrain; load = (kappa < cfg->kappa_i) ? 0 : 1; }
+  else { kappa = kappa0; load = 0; }
+  const double omega = damage_evolution(cfg, kappa);
+  double stiff[MAXSTR * MAXSTR];
+  for (int i = 0; i < n * n; i++) stiff[i] = (1.0 - omega) * stiff0[i];
+  matvec(n, stiff, strain, stress);
+  *hist_new = load ? -kappa : kappa;
+}
+
+static int gd_check(const fo_config* cfg, const shape_t* sh) {
+  if (cfg->model != FO_GRADIENT_DAMAGE || cfg->material != FO_DAMAGE) FAIL("GradientDamage tables need the GradientDamage model with the Damage material");
+  if (cfg->eqv_strain == FO_EQV_VONMISES && sh->rank != 3) FAIL("eqvStrain = vonMises: rank 3 only");
+  return 0;
+}
+
+/* getStress_ (GradientDamageModel.cpp:956-1063): per Gauss point `material_->update(stressIp, stiff, strain_(ALL,ipoint),
+ * ipoint)` with all strCount + 1 rows of the cache, so the nonlocal branch; N (x) stressIp summed per element, then
+ * added to the node rows.  strain: [nip_total][strCount + 1].  hist_new is rewritten, as the reference's update does. */
+int fo_gd_stress_table(const fo_config* cfg, int64_t nel, const int32_t* conn, const double* strain,
+                       const double* hist_pre, double* hist_new, double* table, double* weights) {
+  shape_t s;
+  if (shape_init(&s, cfg->shape)) return -1;
+  if (gd_check(cfg, &s)) return -1;
+  const int str = STRAIN_COUNTS[s.rank], srows = str + 1;
+  double stiff0[MAXSTR * MAXSTR];
+  if (hooke_stiff(s.rank, cfg->state, cfg->young, cfg->poisson, stiff0)) return -1;
+  int64_t ipoint = 0;
+  for (int64_t ie = 0; ie < nel; ie++) {
+    double ndStress[MAXNPE][6], ndWeights[MAXNPE];
+    for (int a = 0; a < s.npe; a++) { ndWeights[a] = 0.0; for (int c = 0; c < str; c++) ndStress[a][c] = 0.0; }
+    for (int ip = 0; ip < s.nip; ip++, ipoint++) {
+      double stressIp[MAXSTR];
+      damage_update_point(cfg, s.rank, stiff0, strain + ipoint * srows, srows, hist_pre[ipoint], stressIp, hist_new + ipoint);
+      for (int a = 0; a < s.npe; a++) {
+        for (int c = 0; c < str; c++) ndStress[a][c] += s.N[ip][a] * stressIp[c];
+        ndWeights[a] += s.N[ip][a];
+      }
+    }
+    for (int a = 0; a < s.npe; a++) {
+      const int64_t n = conn[ie * s.npe + a];
+      weights[n] += ndWeights[a];
+      for (int c = 0; c < str; c++) table[n * str + c] += ndStress[a][c];
+    }
+  }
+  return 0;
+}
+
+/* getStrain_ (GradientDamageModel.cpp:1071-1177): strCount + 1 columns, the last one "e_eq" (:1135), all rows of the
+ * cache extrapolated (:1161).  The column switch (:1097-1131) has no case 4: in 2-D (strCount = 4) the reference throws
+ * "unexpected number of strain components: 4", and so does this. */
+int fo_gd_strain_table(const fo_config* cfg, int64_t nel, const int32_t* conn, const double* strain,
+                       double* table, double* weights) {
+  shape_t s;
+  if (shape_init(&s, cfg->shape)) return -1;
+  if (gd_check(cfg, &s)) return -1;
+  const int str = STRAIN_COUNTS[s.rank], srows = str + 1;
+  if (str != 1 && str != 3 && str != 6) FAIL("unexpected number of strain components: %d", str);
+  int64_t ipoint = 0;
+  for (int64_t ie = 0; ie < nel; ie++) {
+    double ndStrain[MAXNPE][7], ndWeights[MAXNPE];
+    for (int a = 0; a < s.npe; a++) { ndWeights[a] = 0.0; for (int c = 0; c < srows; c++) ndStrain[a][c] = 0.0; }
+    for (int ip = 0; ip < s.nip; ip++, ipoint++)
+      for (int a = 0; a < s.npe; a++) {
+        for (int c = 0; c < srows; c++) ndStrain[a][c] += s.N[ip][a] * strain[ipoint * srows + c];
+        ndWeights[a] += s.N[ip][a];
+      }
+    for (int a = 0; a < s.npe; a++) {
+      const int64_t n = conn[ie * s.npe + a];
+      weights[n] += ndWeights[a];
+      for (int c = 0; c < srows; c++) table[n * srows + c] += ndStrain[a][c];
+    }
+  }
+  return 0;
+}
+
+/* getDamage_ (GradientDamageModel.cpp:1184-1241): one column "hist"; hist = material_->giveOmega() =
+ * damageEvolution_(newHist_.eqveps[i]) (DamageMaterial.cpp:533-545); the ABSOLUTE values of the shape functions weigh
+ * both the values and the weights (:1233-1234). */
+int fo_gd_damage_table(const fo_config* cfg, int64_t nel, const int32_t* conn, const double* hist_new,
+                       double* table, double* weights) {
+  shape_t s;
+  if (shape_init(&s, cfg->shape)) return -1;
+  if (gd_check(cfg, &s)) return -1;
+  int64_t ipoint = 0;
+  for (int64_t ie = 0; ie < nel; ie++) {
+    double ndHistory[MAXNPE], ndWeights[MAXNPE];
+    for (int a = 0; a < s.npe; a++) { ndWeights[a] = 0.0; ndHistory[a] = 0.0; }
+    for (int ip = 0; ip < s.nip; ip++, ipoint++) {
+      const double h = damage_evolution(cfg, fabs(hist_new[ipoint]));
+      for (int a = 0; a < s.npe; a++) { ndHistory[a] += fabs(s.N[ip][a]) * h; ndWeights[a] += fabs(s.N[ip][a]); }
+    }
+    for (int a = 0; a < s.npe; a++) {
+      const int64_t n = conn[ie * s.npe + a];
+      weights[n] += ndWeights[a];
+      table[n] += ndHistory[a];
+    }
+  }
+  return 0;
+}
+
+/* getOutputData_ (GradientDamageModel.cpp:1254-1365): point values [strain.tensor | stress.tensor | damage] (TbFiller's
+ * announce order, :1270-1273: 2 strCount + 1 of them).  The damage is giveOmega() taken BEFORE the loop (:1316); the
+ * stress comes from `update(stress, stiff, strain, ipoint)` with strain = the first strCount rows of the cache (:1340,
+ * :1343): stress and strain have the same size, so the material takes its LOCAL branch and computes the equivalent
+ * strain from the strain itself -- and rewrites newHist_ with the outcome.  cols: TbFiller's i2table (:1347). */
+int fo_gd_output_data(const fo_config* cfg, int64_t nel, const int32_t* conn, const double* strain,
+                      const double* hist_pre, double* hist_new, int ncols, const int32_t* cols,
+                      double* table, double* weights) {
+  shape_t s;
+  if (shape_init(&s, cfg->shape)) return -1;
+  if (gd_check(cfg, &s)) return -1;
+  const int str = STRAIN_COUNTS[s.rank], srows = str + 1, ntype = 2 * str + 1;
+  for (int j = 0; j < ncols; j++) if (cols[j] < 0 || cols[j] >= ntype) FAIL("column %d out of range", cols[j]);
+  double stiff0[MAXSTR * MAXSTR];
+  if (hooke_stiff(s.rank, cfg->state, cfg->young, cfg->poisson, stiff0)) return -1;
+  const int64_t npoint = nel * s.nip;
+  double* hist = (double*)malloc(sizeof(double) * (size_t)(npoint > 0 ? npoint : 1));
+  if (!hist) FAIL("out of memory");
+  for (int64_t i = 0; i < npoint; i++) hist[i] = damage_evolution(cfg, fabs(hist_new[i]));
+  int64_t igpoint = 0;
+  for (int64_t ie = 0; ie < nel; ie++) {
+    double ndValuesOut[MAXNPE][13], ndWeights[MAXNPE], ipValues[13];
+    for (int a = 0; a < s.npe; a++) { ndWeights[a] = 0.0; for (int j = 0; j < ncols; j++) ndValuesOut[a][j] = 0.0; }
+    for (int ip = 0; ip < s.nip; ip++, igpoint++) {
+      for (int c = 0; c < str; c++) ipValues[c] = strain[igpoint * srows + c];
+      ipValues[2 * str] = hist[igpoint];
+      damage_update_point(cfg, s.rank, stiff0, ipValues, str, hist_pre[igpoint], ipValues + str, hist_new + igpoint);
+      for (int a = 0; a < s.npe; a++) {
+        for (int j = 0; j < ncols; j++) ndValuesOut[a][j] += s.N[ip][a] * ipValues[cols[j]];
+        ndWeights[a] += s.N[ip][a];
+      }
+    }
+    for (int a = 0; a < s.npe; a++) {
+      const int64_t n = conn[ie * s.npe + a];
+      weights[n] += ndWeights[a];
+      for (int j = 0; j < ncols; j++) table[n * ncols + j] += ndValuesOut[a][j];
+    }
+  }
+  free(hist);
+  return 0;
+}
+
 int fo_assemble(const fo_config* cfg,
                 int nnode, const double* coords,
                 int64_t nel, const int32_t* conn,

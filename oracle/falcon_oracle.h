@@ -111,6 +111,18 @@ int fo_stress_table(const fo_config* cfg, int64_t nel, const int32_t* conn, cons
                     double* table, double* weights);
 
 /* Psi0 = initial history value, PhaseFractureModel.cpp:296-359 */
+/* GradientDamageModel's tables (GradientDamageModel.cpp:956-1365): getStress_, getStrain_ (3-D only: the reference
+ * throws in 2-D), getDamage_, getOutputData_.  strain: [nip_total][strCount + 1]; hist_*: kappa, negative = loading. */
+int fo_gd_stress_table(const fo_config* cfg, int64_t nel, const int32_t* conn, const double* strain,
+                       const double* hist_pre, double* hist_new, double* table, double* weights);
+int fo_gd_strain_table(const fo_config* cfg, int64_t nel, const int32_t* conn, const double* strain,
+                       double* table, double* weights);
+int fo_gd_damage_table(const fo_config* cfg, int64_t nel, const int32_t* conn, const double* hist_new,
+                       double* table, double* weights);
+int fo_gd_output_data(const fo_config* cfg, int64_t nel, const int32_t* conn, const double* strain,
+                      const double* hist_pre, double* hist_new, int ncols, const int32_t* cols,
+                      double* table, double* weights);
+
 double fo_psi0(const fo_config* cfg);
 
 /* degradation function g, g', g'' at phi (PhaseFractureModel.cpp:660-676); g carries the +1e-7 */

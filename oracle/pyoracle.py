@@ -78,6 +78,10 @@ def lib():
                                   ip64, ip32, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp]
         L.fo_strain_table.argtypes = [C.c_int, C.c_int64, ip32, dp, C.c_int, C.c_int, dp, dp]
         L.fo_stress_table.argtypes = [C.POINTER(Config), C.c_int64, ip32, dp, C.c_int, dp, dp]
+        L.fo_gd_stress_table.argtypes = [C.POINTER(Config), C.c_int64, ip32, dp, dp, dp, dp, dp]
+        L.fo_gd_strain_table.argtypes = [C.POINTER(Config), C.c_int64, ip32, dp, dp, dp]
+        L.fo_gd_damage_table.argtypes = [C.POINTER(Config), C.c_int64, ip32, dp, dp, dp]
+        L.fo_gd_output_data.argtypes = [C.POINTER(Config), C.c_int64, ip32, dp, dp, dp, C.c_int, ip32, dp, dp]
         L.fo_last_error.restype = C.c_char_p
         L.fo_mazars.argtypes = [C.POINTER(Config), C.c_int, dp, dp, dp, dp]
         L.fo_vonmises.argtypes = [C.POINTER(Config), dp, dp, dp]
@@ -132,6 +136,56 @@ def stress_table(cfg, nnode, conn, strain):
     if rc != 0:
         raise ValueError(lib().fo_last_error().decode())
     return table, weights
+
+
+def _gd_common(cfg, conn, *arrs):
+    rank = shape_info(cfg.shape)[0]
+    conn = np.ascontiguousarray(conn, dtype=np.int32)
+    return (rank, 4 if rank == 2 else 6, conn) + tuple(np.ascontiguousarray(a, dtype=np.float64) for a in arrs)
+
+
+def _gd_rc(rc):
+    if rc != 0:
+        raise ValueError(lib().fo_last_error().decode())
+
+
+def gd_stress_table(cfg, nnode, conn, strain, hist_pre):
+    """GradientDamageModel::getStress_: (table[nnode][str], weights[nnode], newHist_ as the update leaves it)."""
+    rank, str_, conn, strain, hist_pre = _gd_common(cfg, conn, strain, hist_pre)
+    table = np.zeros((nnode, str_)); weights = np.zeros(nnode); hist_new = np.zeros_like(hist_pre)
+    _gd_rc(lib().fo_gd_stress_table(C.byref(cfg), conn.shape[0], _p(conn, C.c_int32), _p(strain, C.c_double), _p(hist_pre, C.c_double),
+                                    _p(hist_new, C.c_double), _p(table, C.c_double), _p(weights, C.c_double)))
+    return table, weights, hist_new
+
+
+def gd_strain_table(cfg, nnode, conn, strain):
+    """GradientDamageModel::getStrain_: (table[nnode][str + 1], weights); ValueError in 2-D like the reference's throw."""
+    rank, str_, conn, strain = _gd_common(cfg, conn, strain)
+    table = np.zeros((nnode, str_ + 1)); weights = np.zeros(nnode)
+    _gd_rc(lib().fo_gd_strain_table(C.byref(cfg), conn.shape[0], _p(conn, C.c_int32), _p(strain, C.c_double),
+                                    _p(table, C.c_double), _p(weights, C.c_double)))
+    return table, weights
+
+
+def gd_damage_table(cfg, nnode, conn, hist_new):
+    """GradientDamageModel::getDamage_: (table[nnode][1], weights) from newHist_, |N| weights."""
+    rank, str_, conn, hist_new = _gd_common(cfg, conn, hist_new)
+    table = np.zeros((nnode, 1)); weights = np.zeros(nnode)
+    _gd_rc(lib().fo_gd_damage_table(C.byref(cfg), conn.shape[0], _p(conn, C.c_int32), _p(hist_new, C.c_double),
+                                    _p(table, C.c_double), _p(weights, C.c_double)))
+    return table, weights
+
+
+def gd_output_data(cfg, nnode, conn, strain, hist_pre, hist_new, cols):
+    """GradientDamageModel::getOutputData_: columns `cols` of [strain.tensor | stress.tensor | damage];
+    returns (table, weights, newHist_ as the local update leaves it)."""
+    rank, str_, conn, strain, hist_pre = _gd_common(cfg, conn, strain, hist_pre)
+    hist_new = np.array(hist_new, dtype=np.float64)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    table = np.zeros((nnode, cols.size)); weights = np.zeros(nnode)
+    _gd_rc(lib().fo_gd_output_data(C.byref(cfg), conn.shape[0], _p(conn, C.c_int32), _p(strain, C.c_double), _p(hist_pre, C.c_double),
+                                   _p(hist_new, C.c_double), cols.size, _p(cols, C.c_int32), _p(table, C.c_double), _p(weights, C.c_double)))
+    return table, weights, hist_new
 
 
 def ndof_per_node(model, rank):

@@ -283,6 +283,64 @@ def test_refusals():
 
 
 # ---------------------------------------------------------------- GPU parity ----------------------------------------------------------------
+def test_tables_of_a_uniform_element_closed_form():
+    """getStress_ / getDamage_ / getOutputData_ / getStrain_ (GradientDamageModel.cpp:956-1365) on one uniformly strained
+    element: nodal value / weight is the Gauss-point value.  getStress_ takes kappa from the cached NONLOCAL strain,
+    getOutputData_ hands the material a strain of stress size, so its stress uses the LOCAL equivalent strain (:1340-1343
+    with DamageMaterial.cpp:370-373) while its damage column is giveOmega() of the history the last pass left (:1316)."""
+    coords, conn = meshgen.grid_quad4(1, 1)
+    rp, ci = po.pattern(4, conn, 3, 2)
+    e, k = 8e-3, 2.5e-3
+    cfg = gd_config(po.QUAD4_G2, po.SOFT_EXPONENTIAL2)
+    Ki, Kc = 1e-3, 6e-3
+    om = lambda kk: 0.0 if kk < Ki else 1 - Ki / kk * np.exp((Ki - kk) / (Kc - Ki))
+    st = np.zeros(12); st[0::3] = e * coords[:, 0]; st[2::3] = k
+    hpre = np.full(4, 1.5e-3)
+    out = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=hpre, want_strain=True)
+    a = E / ((1 + NU) * (1 - 2 * NU)); D00 = a * (1 - NU); D01 = a * NU
+    t, w, hn = po.gd_stress_table(cfg, 4, conn, out["strain"], hpre)
+    assert np.allclose(w, 1.0, rtol=1e-14) and np.array_equal(hn, out["hist_new"])
+    assert np.allclose(t / w[:, None], (1 - om(k)) * np.array([D00 * e, D01 * e, D01 * e, 0.0]), rtol=1e-12, atol=1e-15)
+    td, wd = po.gd_damage_table(cfg, 4, conn, out["hist_new"])
+    assert np.allclose(td[:, 0] / wd, om(k), rtol=1e-13)
+    eq_local = 0.5 * D00 * e * e                                           # 6.7e-3 > k: the local branch loads further
+    assert eq_local > k
+    to, wo, hl = po.gd_output_data(cfg, 4, conn, out["strain"], hpre, out["hist_new"], np.arange(9))
+    assert np.allclose(to[:, 0:4] / wo[:, None], [e, 0, 0, 0], rtol=1e-12, atol=1e-17)
+    assert np.allclose(to[:, 4:8] / wo[:, None], (1 - om(eq_local)) * np.array([D00 * e, D01 * e, D01 * e, 0.0]), rtol=1e-12, atol=1e-15)
+    assert np.allclose(to[:, 8] / wo, om(k), rtol=1e-13)                   # damage column: the history BEFORE the local update
+    assert np.allclose(hl, -eq_local, rtol=1e-13)                          # ... which newHist_ holds afterwards
+    sub, _, _ = po.gd_output_data(cfg, 4, conn, out["strain"], hpre, out["hist_new"], [8, 4])
+    assert np.array_equal(sub, to[:, [8, 4]])
+    with pytest.raises(ValueError, match="unexpected number of strain components: 4"):   # the reference's switch has no case 4
+        po.gd_strain_table(cfg, 4, conn, out["strain"])
+    # 3-D: strCount + 1 columns, the last one the nonlocal equivalent strain
+    c3, n3 = meshgen.grid_hex8(1, 1, 1)
+    rp3, ci3 = po.pattern(8, n3, 4, 3)
+    cfg3 = gd_config(po.HEX8_G2, po.SOFT_EXPONENTIAL2)
+    s3 = np.zeros(32); s3[0::4] = e * c3[:, 0]; s3[3::4] = k
+    o3 = po.assemble(cfg3, c3, n3, rp3, ci3, s3, hist_pre=np.full(8, 1.5e-3), want_strain=True)
+    t3, w3 = po.gd_strain_table(cfg3, 8, n3, o3["strain"])
+    assert t3.shape == (8, 7) and np.allclose(t3 / w3[:, None], [e, 0, 0, 0, 0, 0, k], rtol=1e-12, atol=1e-17)
+
+
+def test_damage_table_weighs_with_absolute_shape_functions():
+    """getDamage_ (:1233-1234) uses abs(sfuncs): on a Quad8 the corner functions are negative at the Gauss points, so the
+    weights differ from getStress_'s, and value / weight still is omega for a uniform history."""
+    coords, conn = meshgen.grid_quad8(2, 1)
+    cfg = gd_config(po.QUAD8_G3, po.SOFT_LINEAR2)
+    nip = po.shape_info(po.QUAD8_G3)[2]
+    hist = np.full(conn.shape[0] * nip, -2.5e-3)
+    td, wd = po.gd_damage_table(cfg, coords.shape[0], conn, hist)
+    assert np.allclose(td[:, 0] / wd, (2.5e-3 - 1e-3) / (4e-3 - 1e-3), rtol=1e-13)
+    N = po.shape_tables(po.QUAD8_G3)[0]                                    # [nip][npe]
+    wref = np.zeros(coords.shape[0])
+    for el in conn:
+        wref[el] += np.abs(N).sum(axis=0)
+    assert np.allclose(wd, wref, rtol=1e-14)
+    assert (N < 0).any() and not np.allclose(wref, np.bincount(conn.ravel(), np.tile(N.sum(axis=0), conn.shape[0])))
+
+
 GPU_MESH = {po.TRI3_G1: lambda: meshgen.grid_tri3(9, 7), po.QUAD4_G2: lambda: meshgen.grid_quad4(11, 9),
             po.HEX8_G2: lambda: meshgen.grid_hex8(5, 4, 3), po.TRI6_G3: lambda: meshgen.grid_tri6(6, 5),
             po.QUAD8_G3: lambda: meshgen.grid_quad8(7, 5), po.HEX20_G2: lambda: meshgen.grid_hex20(3, 3, 3)}
@@ -416,3 +474,103 @@ def test_gpu_gradient_damage_deterministic_and_generic_paths(shape):
     asm.assemble(dst, None, f3, flags=capi.OVERWRITE | capi.DETERMINISTIC)
     torch.cuda.synchronize()
     assert torch.equal(f2, f3) and (f2 - outs[0][1]).abs().max().item() < 1e-12 * np.abs(ref["f"]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,soft,state2d,eqv", [
+    (po.QUAD4_G2, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN, 0), (po.QUAD4_G2, po.SOFT_LINEAR1, po.PLANE_STRESS, 1),
+    (po.TRI3_G1, po.SOFT_EXPONENTIAL1, po.PLANE_STRESS, 1), (po.QUAD8_G3, po.SOFT_HYPERBOLIC, po.PLANE_STRAIN, 0),
+    (po.TRI6_G3, po.SOFT_POWER, po.PLANE_STRAIN, 1), (po.HEX8_G2, po.SOFT_EXPONENTIAL1, po.PLANE_STRAIN, 2),
+    (po.HEX8_G2, po.SOFT_LINEAR2, po.PLANE_STRAIN, 1), (po.HEX20_G2, po.SOFT_EXPONENTIAL2, po.PLANE_STRAIN, 0)])
+def test_gpu_gradient_damage_tables(shape, soft, state2d, eqv):
+    """GET_TABLE of GradientDamageModel (GradientDamageModel.cpp:884-1365) from the device-resident strain cache and
+    histories: getStress_, getDamage_, getOutputData_ and getStrain_ against the oracle's element loops at 1e-12, the
+    tables added to (addBlock), and newHist_ left as the reference's material update leaves it after each of them."""
+    import torch
+    from falcon_amd import capi
+    TOL = 1e-12
+    rank, npe, nip, _ = po.shape_info(shape)
+    str_ = 4 if rank == 2 else 6
+    coords, conn = GPU_MESH[shape]()
+    coords = meshgen.distort(coords, conn, 0.15 if shape in (po.TRI3_G1, po.QUAD4_G2, po.HEX8_G2) else 0.06, 1)
+    coords, conn, _ = meshgen.shuffle_nodes(coords, conn, 5)
+    nn = coords.shape[0]
+    cfg = gd_config(shape, soft, state2d, eqv=eqv)
+    st = gd_state(coords, rank)
+    # local equivalent strain (getOutputData_'s branch) in the range of the cached nonlocal one and of kappaI .. kappaC;
+    # far beyond kappaC the laws' own `1 - omega` loses digits (omega -> 1), in the reference as much as here
+    st.reshape(nn, rank + 1)[:, :rank] *= 0.27
+    H0 = gd_history(conn.shape[0] * nip)
+    asm = capi.Assembler(shape, capi.GRADIENT_DAMAGE, capi.DAMAGE, coords, conn, state=state2d, young=E, poisson=NU,
+                         softening=soft, length_scale=0.02, eqv_strain=eqv, eta=ETA, **LAWS[soft])
+    rp, ci = asm.pattern()
+    dev = torch.device("cuda", 0)
+    asm.set_history(0, H0)
+    f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+    z = lambda *s: torch.full(s, 0.5, dtype=torch.float64, device=dev)
+    with pytest.raises(capi.FaError, match="FA_STORE_STRAIN"):
+        asm.stress_table(z(nn, str_), z(nn))
+    asm.assemble(torch.from_numpy(st).to(dev), None, f, flags=capi.OVERWRITE | capi.STORE_STRAIN)
+    ref = po.assemble(cfg, coords, conn, rp, ci, st, hist_pre=H0, want_K=False, want_strain=True)
+    close = lambda got, want: np.abs(got - want).max() <= TOL * max(np.abs(want).max(), 1e-300)
+
+    def check_cols(got, want):
+        for j in range(want.shape[1]):
+            assert close(got[:, j], want[:, j]), j
+
+    # getDamage_: omega of newHist_, |N| weights
+    t, w = z(nn), z(nn)
+    asm.damage_table(t, w)
+    td, wd = po.gd_damage_table(cfg, nn, conn, ref["hist_new"])
+    assert close(t.cpu().numpy() - 0.5, td[:, 0]) and close(w.cpu().numpy() - 0.5, wd)
+    assert td.max() > 0.05
+    # getStress_: nonlocal branch; newHist_ rewritten with the same outcome as the assembly pass
+    t, w = z(nn, str_), z(nn)
+    asm.stress_table(t, w)
+    ts, ws, hs = po.gd_stress_table(cfg, nn, conn, ref["strain"], H0)
+    check_cols(t.cpu().numpy() - 0.5, ts)
+    assert close(w.cpu().numpy() - 0.5, ws)
+    assert np.array_equal(hs, ref["hist_new"])
+    got_h = asm.get_history(1)
+    assert np.array_equal(got_h < 0, hs < 0) and close(got_h, hs)
+    if rank == 2:
+        assert (np.abs(ts[:, 2]).max() == 0.0) == (state2d == po.PLANE_STRESS)
+    # getStrain_: e_eq column in 3-D, the reference's throw in 2-D
+    if rank == 3:
+        t, w = z(nn, str_ + 1), z(nn)
+        asm.strain_table(t, w)
+        te, we = po.gd_strain_table(cfg, nn, conn, ref["strain"])
+        check_cols(t.cpu().numpy() - 0.5, te)
+        assert close(w.cpu().numpy() - 0.5, we)
+    else:
+        with pytest.raises(capi.FaError, match="unexpected number of strain components: 4"):
+            asm.strain_table(z(nn, str_ + 1), z(nn))
+    # getOutputData_: local branch for the stress, damage column from newHist_ before the call; newHist_ afterwards
+    for cols in (list(range(2 * str_ + 1)), [2 * str_, str_ + 1, 0]):
+        asm.set_history(1, ref["hist_new"])
+        t, w = z(nn, len(cols)), z(nn)
+        asm.output_data(cols, t, w)
+        to, wo, hl = po.gd_output_data(cfg, nn, conn, ref["strain"], H0, ref["hist_new"], cols)
+        check_cols(t.cpu().numpy() - 0.5, to)
+        assert close(w.cpu().numpy() - 0.5, wo)
+        got_h = asm.get_history(1)
+        assert np.array_equal(got_h < 0, hl < 0) and close(got_h, hl)
+    assert not np.array_equal(hl, ref["hist_new"])                       # the local update really differs from the nonlocal one
+    # ... and getDamage_ after getOutputData_ sees the locally updated history, as the reference's would
+    t, w = z(nn), z(nn)
+    asm.damage_table(t, w)
+    td2, _ = po.gd_damage_table(cfg, nn, conn, hl)
+    assert close(t.cpu().numpy() - 0.5, td2[:, 0])
+    with pytest.raises(capi.FaError, match="out of range"):
+        asm.output_data([2 * str_ + 1], z(nn, 1), z(nn))
+
+
+@pytest.mark.gpu
+def test_gpu_damage_table_is_gradient_damage_only():
+    import torch
+    from falcon_amd import capi
+    coords, conn = meshgen.grid_quad4(3, 3)
+    asm = capi.Assembler(capi.QUAD4_G2, capi.PHASE_FRACTURE, capi.AMOR_PHASE, coords, conn, young=E, poisson=NU, gc=2.7e-3, l0=0.2)
+    dev = torch.device("cuda", 0)
+    with pytest.raises(capi.FaError, match="GradientDamage"):
+        asm.damage_table(torch.zeros(asm.nnode, dtype=torch.float64, device=dev), torch.zeros(asm.nnode, dtype=torch.float64, device=dev))
