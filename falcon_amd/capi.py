@@ -60,7 +60,8 @@ EXPORTS = ["fa_create", "fa_destroy", "fa_last_error", "fa_ndof", "fa_nnz", "fa_
            "fa_strain_rows", "fa_uses_row_kernel", "fa_psi0", "fa_patch_stats", "fa_pattern_host", "fa_pattern_device",
            "fa_assemble", "fa_assemble_noalloc", "fa_assemble_host", "fa_commit", "fa_get_history", "fa_set_history",
            "fa_history_device", "fa_get_strain_cache", "fa_shape_info", "fa_shape_tables", "fa_gather_sum", "fa_strain_table", "fa_stress_table", "fa_damage_table",
-           "fa_pattern_device32", "fa_device", "fa_cons_create", "fa_cons_destroy", "fa_cons_set_rvalues", "fa_cons_eliminate",
+           "fa_pattern_device32", "fa_device", "fa_cons_create", "fa_cons_destroy", "fa_cons_set_rvalues", "fa_cons_eliminate", "fa_cons_eliminate_out", "fa_cons_fill_in", "fa_cons_nnz",
+           "fa_cons_pattern_device", "fa_cons_pattern_device32", "fa_cons_pattern_host",
            "fa_cons_eval_masters", "fa_cons_eval_slaves", "fa_residual", "fa_arc_func", "fa_output_data", "fa_micro_stale_hits", "fa_set_interface"]
 
 _lib = None
@@ -116,6 +117,12 @@ def lib():
         L.fa_cons_destroy.argtypes = [vp]; L.fa_cons_destroy.restype = None
         L.fa_cons_set_rvalues.argtypes = [vp, vp, vp]
         L.fa_cons_eliminate.argtypes = [vp, vp, vp, vp]
+        L.fa_cons_eliminate_out.argtypes = [vp, vp, vp, vp, vp]
+        L.fa_cons_fill_in.argtypes = [vp]; L.fa_cons_fill_in.restype = C.c_int64
+        L.fa_cons_nnz.argtypes = [vp]; L.fa_cons_nnz.restype = C.c_int64
+        L.fa_cons_pattern_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+        L.fa_cons_pattern_device32.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+        L.fa_cons_pattern_host.argtypes = [vp, vp, vp]
         L.fa_cons_eval_masters.argtypes = [vp, vp, vp]
         L.fa_cons_eval_slaves.argtypes = [vp, vp, vp]
         L.fa_residual.argtypes = [vp] * 11
@@ -399,6 +406,35 @@ class Constraints:
     def eliminate(self, K, rhs=None, stream=None):
         """K := T^t K T + I_S, rhs := T^t (rhs - K c), in place (StdConstrainer, cuDSSSolver.cpp:108-121,293)."""
         _check(lib().fa_cons_eliminate(self.h, self._ptr(K, self.asm.nnz), self._ptr(rhs, self.asm.ndof), self._stream(stream)))
+
+    @property
+    def fill_in(self):
+        """entries of the constrained matrix outside the assembler's pattern (0: eliminate() works in place)"""
+        return int(lib().fa_cons_fill_in(self.h))
+
+    @property
+    def nnz(self):
+        return int(lib().fa_cons_nnz(self.h))
+
+    def pattern(self):
+        """host copy (row_ptr int64, col_idx int32) of the output pattern: the assembler's plus the fill-in"""
+        rp = np.empty(self.asm.ndof + 1, dtype=np.int64); ci = np.empty(max(1, self.nnz), dtype=np.int32)
+        _check(lib().fa_cons_pattern_host(self.h, _np_ptr(rp), _np_ptr(ci)))
+        return rp, ci[:self.nnz]
+
+    def pattern_device32(self):
+        rp = C.c_void_p(); ci = C.c_void_p()
+        _check(lib().fa_cons_pattern_device32(self.h, C.byref(rp), C.byref(ci)))
+        return rp.value, ci.value
+
+    def eliminate_out(self, K, rhs=None, out=None, stream=None):
+        """K_out := T^t K T + I_S on the output pattern (fa_cons_nnz entries), rhs := T^t (rhs - K c) in place; returns K_out."""
+        import torch
+        if out is None:
+            out = torch.empty(self.nnz, dtype=torch.float64, device=K.device)
+        _check(lib().fa_cons_eliminate_out(self.h, self._ptr(K, self.asm.nnz), self._ptr(out, self.nnz), self._ptr(rhs, self.asm.ndof),
+                                           self._stream(stream)))
+        return out
 
     def eval_masters(self, vec, stream=None):
         _check(lib().fa_cons_eval_masters(self.h, self._ptr(vec, self.asm.ndof), self._stream(stream)))

@@ -309,15 +309,28 @@ int32_t   fa_device(const fa_ctx* ctx);
  * DispArclenBCs.cpp:358,440,494, PeriodicModel.cpp:287, GradientDamageModel.cpp:843, StaggeredModule.cpp:767-1031):
  *     u[slave_dofs[k]] = rvalues[k] + sum_{q = master_ptr[k]}^{master_ptr[k+1]-1} master_coefs[q] * u[master_dofs[q]]
  * HOST arrays; rvalues NULL => 0; master_ptr NULL => no masters (plain Dirichlet conditions).  A master must not be a
- * slave (the compressed form, Constraints::compress).  The pattern of the context must hold every entry the
- * elimination writes -- (j, master) for every stored (j, slave), (master, q) for every stored (slave, q), the slaves'
- * diagonal -- otherwise FA_ERR_ARG names the missing entry; plain Dirichlet conditions never need extra entries.
- * The constraint set is tied to the context's pattern and device; destroy it before the context. */
+ * slave (the compressed form, Constraints::compress).
+ * The elimination writes (j, master) for every stored (j, slave), (master, q) for every stored (slave, q) and the slaves'
+ * diagonal.  Plain Dirichlet conditions never need entries the pattern lacks; periodic / tied / arc-length constraints
+ * usually do.  Like StdConstrainer, which builds a new matrix structure (cuDSSSolver.cpp:108-121 getOutputMatrix), the
+ * constraint set then owns an OUTPUT pattern: the context's pattern plus that fill-in (merged into the rows by column
+ * where the row is column-sorted, appended to the row otherwise).  fa_cons_fill_in says how many entries were added (0:
+ * the output pattern IS the context's and fa_cons_eliminate works in place), fa_cons_nnz the size of the output
+ * matrix, fa_cons_pattern_* hand it out (64- and 32-bit offsets, device; host copy), fa_cons_eliminate_out fills it.
+ * Set-up cost: one device scan of the nnz column indices (HBM speed, no copy of the pattern to the host) plus host work
+ * and memory proportional to the rows the constraints touch; with fill-in, nnz + fill int32 of device memory for the
+ * output columns and ndof + 1 int64 for its offsets.  The constraint set is tied to the context's pattern and device;
+ * destroy it before the context. */
 typedef struct fa_cons fa_cons;
 fa_status fa_cons_create(fa_ctx* ctx, int64_t nslave, const int64_t* slave_dofs, const double* rvalues,
                          const int64_t* master_ptr, const int64_t* master_dofs, const double* master_coefs,
                          fa_cons** out);
 void      fa_cons_destroy(fa_cons* cons);
+int64_t   fa_cons_fill_in(const fa_cons* cons);
+int64_t   fa_cons_nnz(const fa_cons* cons);
+fa_status fa_cons_pattern_device(const fa_cons* cons, const int64_t** row_ptr, const int32_t** col_idx);
+fa_status fa_cons_pattern_device32(fa_cons* cons, const int32_t** row_ptr, const int32_t** col_idx);
+fa_status fa_cons_pattern_host(const fa_cons* cons, int64_t* row_ptr, int32_t* col_idx);
 /* new right-hand values (they change with every load step, DispArclenBCs.cpp:494); host array of nslave doubles */
 fa_status fa_cons_set_rvalues(fa_cons* cons, const double* rvalues, void* stream);
 
@@ -329,6 +342,12 @@ fa_status fa_cons_set_rvalues(fa_cons* cons, const double* rvalues, void* stream
  * Only the entries in slave rows / columns and their fold destinations are touched: O(boundary) per call.  No atomics;
  * bitwise repeatable.  After the solve, fa_cons_eval_slaves gives the slave entries of the solution (:416 getLhs). */
 fa_status fa_cons_eliminate(const fa_cons* cons, double* K_values, double* rhs, void* stream);
+/* The same into the output pattern: K_out (fa_cons_nnz doubles, device) = K_values copied to its places in the output
+ * pattern, fill-in zero, then eliminated there; K_values is left as it is, rhs is updated in place.  Works with and
+ * without fill-in (without: a plain copy, or in place when K_out == K_values); with fill-in fa_cons_eliminate itself
+ * answers FA_ERR_ARG.  The copy reads and writes every entry once: 16 bytes per non-zero on top of the O(boundary)
+ * elimination -- what the reference's constrainer does on the host every time the matrix changes. */
+fa_status fa_cons_eliminate_out(const fa_cons* cons, const double* K_values, double* K_out, double* rhs, void* stream);
 /* jive::util::evalMasterDofs (BFGSModule.cpp:443, LodiModel.cpp:265, TSArclenModule.cpp:520,641): vec[master] +=
  * coef * vec[slave], vec[slave] = 0.  Device vector of ndof doubles. */
 fa_status fa_cons_eval_masters(const fa_cons* cons, double* vec, void* stream);

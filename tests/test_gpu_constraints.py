@@ -135,10 +135,103 @@ def test_eliminate_matches_oracle(case, need_fill):
     cons.close(); asm.close()
 
 
-def test_missing_fill_in_and_bad_constraints_are_refused():
-    asm, cs, K, f, dev = setup(periodic_case, False)              # canonical pattern: no (j, master) entries
-    with pytest.raises(capi.FaError, match="has no entry"):
-        asm.constraints(cs["slave"], cs["rval"], cs["mptr"], cs["mdof"], cs["mcoef"])
+def scatter_into(rp, ci, K, rpo, cio):
+    """values of a CSR matrix placed into a pattern that contains its own; the new entries zero"""
+    n = rp.size - 1
+    out = np.zeros(cio.size)
+    for r in range(n):
+        pos = {int(c): q for q, c in zip(range(rpo[r], rpo[r + 1]), cio[rpo[r]:rpo[r + 1]])}
+        for p in range(rp[r], rp[r + 1]):
+            out[pos[int(ci[p])]] = K[p]
+    return out
+
+
+@pytest.mark.parametrize("case", [periodic_case, tied_case])
+@pytest.mark.parametrize("shuffled_rows", [False, True])
+def test_fill_in_is_built_by_the_constraint_set(case, shuffled_rows):
+    """Constraints with masters on the assembler's own pattern: what StdConstrainer's new matrix structure holds
+    (cuDSSSolver.cpp:108-121) is laid out by fa_cons_create -- the canonical pattern plus the fill-in, rows kept sorted by
+    column (or, for a caller's pattern with unsorted rows, the fill-in appended to the row) -- and fa_cons_eliminate_out
+    fills it: against the oracle's elimination on that pattern, and against the assembler given the pre-extended pattern."""
+    import torch
+    kw = {}
+    if shuffled_rows:                                             # a caller's pattern whose rows are not sorted by column
+        coords, conn = meshgen.grid_quad4(14, 9)
+        rp0, ci0 = po.pattern(coords.shape[0], conn, 3, 2)
+        ci0 = ci0.copy(); rng = np.random.default_rng(3)
+        for r in range(rp0.size - 1):
+            ci0[rp0[r]:rp0[r + 1]] = rng.permutation(ci0[rp0[r]:rp0[r + 1]])
+        kw = dict(row_ptr=rp0, col_idx=ci0)
+    coords, conn = meshgen.grid_quad4(14, 9)
+    coords = meshgen.distort(coords, conn, 0.05, 3)
+    nd = 3
+    cs = case(coords, nd)
+    asm = capi.Assembler(capi.QUAD4_G2, capi.PHASE_FRACTURE, capi.AMOR_PHASE, coords, conn, keep_off_diags=True, **KW, **kw)
+    dev = torch.device("cuda", 0)
+    st = meshgen.smooth_state(coords, nd, seed=2, amp=5e-3, noise=1e-4, l0=0.3)
+    K = torch.zeros(asm.nnz, dtype=torch.float64, device=dev); f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+    asm.assemble(torch.from_numpy(st).to(dev), K, f, flags=capi.OVERWRITE)
+    rp, ci = asm.pattern()
+    cons = asm.constraints(cs["slave"], cs.get("rval"), cs["mptr"], cs["mdof"], cs["mcoef"])
+    assert cons.fill_in > 0 and cons.nnz == asm.nnz + cons.fill_in
+    with pytest.raises(capi.FaError, match="fa_cons_eliminate_out"):
+        cons.eliminate(K.clone(), (-f).clone())                   # in place: no room for the fill-in
+    rpo, cio = cons.pattern()
+    n = asm.ndof
+    assert rpo[0] == 0 and rpo[-1] == cons.nnz and np.all(np.diff(rpo) >= np.diff(rp))
+    rpe, cie = extended_pattern(rp, ci, cs)
+    for r in range(n):
+        old = ci[rp[r]:rp[r + 1]]; new = cio[rpo[r]:rpo[r + 1]]
+        assert np.unique(new).size == new.size and set(old) <= set(new) <= set(cie[rpe[r]:rpe[r + 1]])
+        if shuffled_rows:
+            assert np.array_equal(new[:old.size], old)            # the caller's order kept, fill-in behind it
+        else:
+            assert np.all(np.diff(new) > 0)                       # still sorted by column
+    Kh_in = K.cpu().numpy(); rh = -f.cpu().numpy().copy()
+    rhs = (-f).clone(); rhs2 = (-f).clone()
+    Ko = cons.eliminate_out(K, rhs)
+    Ko2 = cons.eliminate_out(K, rhs2)
+    torch.cuda.synchronize()
+    assert np.array_equal(K.cpu().numpy(), Kh_in)                 # the input matrix is left alone
+    assert torch.equal(Ko, Ko2) and torch.equal(rhs, rhs2)
+    Kh = scatter_into(rp, ci, Kh_in, rpo, cio)
+    ref = po.Constraints(cs["slave"], cs.get("rval"), cs["mptr"], cs["mdof"], cs["mcoef"])
+    ref.eliminate(rpo, cio, Kh, rh)                               # raises if the pattern lacked an entry the elimination writes
+    assert np.abs(Ko.cpu().numpy() - Kh).max() <= 1e-12 * np.abs(Kh).max()
+    assert np.abs(rhs.cpu().numpy() - rh).max() <= 1e-12 * np.abs(rh).max()
+    # 32-bit offsets of the output pattern for the solver libraries (cuDSSSolver.cpp:655-663)
+    p_rp, p_ci = cons.pattern_device32()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rp32 = np.empty(n + 1, dtype=np.int32); ci32 = np.empty(cons.nnz, dtype=np.int32)
+    assert hip.hipMemcpy(rp32.ctypes.data, p_rp, rp32.nbytes, 2) == 0 and hip.hipMemcpy(ci32.ctypes.data, p_ci, ci32.nbytes, 2) == 0
+    assert np.array_equal(rp32.astype(np.int64), rpo) and np.array_equal(ci32, cio)
+    if not shuffled_rows:
+        # the same system as from an assembler that was handed the pre-extended pattern
+        asm2, cs2, K2, f2, _ = setup(case, True)
+        cons2 = asm2.constraints(cs2["slave"], cs2.get("rval"), cs2["mptr"], cs2["mdof"], cs2["mcoef"])
+        assert cons2.fill_in == 0
+        rhs3 = (-f2).clone()
+        cons2.eliminate(K2, rhs3)
+        torch.cuda.synchronize()
+        rp2, ci2 = asm2.pattern()
+        A = sp.csr_matrix((Ko.cpu().numpy(), cio, rpo), shape=(n, n)); B = sp.csr_matrix((K2.cpu().numpy(), ci2, rp2), shape=(n, n))
+        assert abs(A - B).max() <= 1e-12 * abs(B).max()
+        assert np.abs(rhs.cpu().numpy() - rhs3.cpu().numpy()).max() <= 1e-12 * np.abs(rh).max()
+        cons2.close(); asm2.close()
+    # without fill-in eliminate_out is the in-place elimination into a copy
+    d = dirichlet_case(coords, nd)
+    cd = asm.constraints(d["slave"], d["rval"])
+    assert cd.fill_in == 0 and cd.nnz == asm.nnz
+    Ka = K.clone(); ra = (-f).clone(); rb = (-f).clone()
+    cd.eliminate(Ka, ra)
+    Kb = cd.eliminate_out(K, rb)
+    assert torch.equal(Ka, Kb) and torch.equal(ra, rb)
+    cd.close(); cons.close(); asm.close()
+
+
+def test_bad_constraints_are_refused():
+    asm, cs, K, f, dev = setup(periodic_case, False)
     with pytest.raises(capi.FaError, match="constrained twice"):
         asm.constraints([3, 4, 3])
     with pytest.raises(capi.FaError, match="out of range"):
