@@ -76,6 +76,7 @@ struct DebugOptions {
   bool no_pair = false;   // FA_NO_PAIR=1: no lane pairs for Quad4
   bool pair_3d = false;   // FA_PAIR_3D=1: lane pairs for Hex8 as well
   int  pad_rec = 1;       // FA_PAD_REC=0: lane records not padded per tile
+  int  pad_tnodes = -1;   // FA_PAD_TNODES=0: node lists of the tile kernel not padded per tile (no early nodal loads)
   bool use_patch = false; // FA_USE_PATCH=1: experimental patch kernel
   int  patch_lds = 0;     // FA_PATCH_LDS=n: doubles of LDS for its CSR image
   bool verbose = false;   // FA_VERBOSE=1: tiling statistics on stderr
@@ -87,7 +88,7 @@ struct DebugOptions {
     o.emat_lpe_f = geti("FA_EMAT_LPE_F", 0); o.fvec = geti("FA_FVEC", -1); o.fvec_blk = geti("FA_FVEC_BLK", 0); o.fvec_cell = geti("FA_FVEC_CELL", -1); o.fvec_atomic = geti("FA_FVEC_ATOMIC", -1);
     o.persist = geti("FA_PERSIST", -1); o.tile_cell = geti("FA_TILE_CELL", -1);
     o.no_pair = getenv("FA_NO_PAIR") != nullptr; o.pair_3d = getenv("FA_PAIR_3D") != nullptr;
-    o.pad_rec = geti("FA_PAD_REC", 1); o.use_patch = getenv("FA_USE_PATCH") != nullptr;
+    o.pad_rec = geti("FA_PAD_REC", 1); o.pad_tnodes = geti("FA_PAD_TNODES", -1); o.use_patch = getenv("FA_USE_PATCH") != nullptr;
     o.patch_lds = geti("FA_PATCH_LDS", 0); o.verbose = getenv("FA_VERBOSE") != nullptr;
     return o;
   }
@@ -384,6 +385,7 @@ struct fa_ctx {
   bool d_first_comp_needed = false;
   unsigned long long* d_stale = nullptr;        // MicroPhaseFracture*: Gauss points of the last call in the `d > 1` branch
   hipEvent_t done_ev = nullptr;                 // recorded at the end of every fa_assemble: what the host getters wait for
+  int tn_stride = 0, tn_strideF = 0;    // padded node lists of the matrix / force-only tile sets (0: not padded)
   double* d_out_tmp = nullptr;         // fa_output_data: strain and stress tables + weights before the column filter
   double* d_arc_part = nullptr;        // fa_arc_func: per-workgroup partial sums of FE_DISSIPATION
   int32_t* d_row_ptr32 = nullptr;      // fa_pattern_device32: the offsets as 32-bit integers, made on first request
@@ -417,6 +419,24 @@ extern "C" void fa_destroy(fa_ctx* c) {
     for (int k = 0; k < 2; k++) if (pl->d[k]) (void)hipFree(pl->d[k]);
   if (c->done_ev) (void)hipEventDestroy(c->done_ev);
   delete c;
+}
+
+// Node lists of a tile set re-laid with a fixed stride per tile (idle slots: node 0), so that the kernel can address a
+// lane's first tile node from the tile index alone (assemble_tiles, "pre").  Returns the stride, 0 when it is not worth
+// it (a tile with more than 1024 nodes would make every list that long).
+static int pad_tile_nodes(fa::TileSet& ts) {
+  int mx = 0;
+  for (int t = 0; t < ts.ntile; t++) mx = std::max(mx, ts.tinfo[(size_t)t * fa::kTileInfo + 1]);
+  if (ts.ntile == 0 || mx > 1024) return 0;
+  const int stride = (mx + 15) & ~15;
+  std::vector<int32_t> padded((size_t)ts.ntile * stride, 0);
+  for (int t = 0; t < ts.ntile; t++) {
+    int32_t* ti = ts.tinfo.data() + (size_t)t * fa::kTileInfo;
+    std::copy(ts.tnodes.begin() + ti[0], ts.tnodes.begin() + ti[0] + ti[1], padded.begin() + (size_t)t * stride);
+    ti[0] = t * stride;
+  }
+  ts.tnodes.swap(padded);
+  return stride;
 }
 
 static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
@@ -920,6 +940,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
                                      nb_ptr.data(), nb.data(), recw, fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0),
                                      budget, P.tile_block, row_order, ts, topt);
       if (c->tile_path) { c->ntile3 = ts.ntile; P.ntile3 = ts.ntile; P.tile_lds = ts.lds_bytes; }
+      if (c->tile_path && (dbg.pad_tnodes >= 0 ? dbg.pad_tnodes != 0 : true)) { c->tn_stride = pad_tile_nodes(ts); P.tn_stride = c->tn_stride; }
       // GET_INT_VECTOR passes keep no records, so a tile set sized for GET_MATRIX0 pays its Gauss-point redundancy for
       // nothing: measured faster than the row / cooperative kernels up to ~3 evaluations per point (Hex20 Gauss3: 5)
       c->tile_force_only = c->tile_path && (env ? true : (ts.point_redundancy < 3.0 && !big));   // big geometry: one workgroup per CU, 1.1 against 0.67 ms for Hex20
@@ -957,6 +978,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
                                   nb_ptr.data(), nb.data(), 0, fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0),
                                   fa::kTileLds, fa::kTileBlock, false, tsT, o);
     if (c->tileF.ok) { c->tileF.ntile = tsT.ntile; c->tileF.lds = tsT.lds_bytes; c->tileF.redundancy = tsT.point_redundancy; c->tileF.block = fa::kTileBlock; }
+    if (c->tileF.ok && (dbg.pad_tnodes >= 0 ? dbg.pad_tnodes != 0 : true)) c->tn_strideF = pad_tile_nodes(tsT);
     if (dbg.verbose)
       fprintf(stderr, "[falcon_assemble] force-only tiles of the tile kernel: %s, %d tiles, %.1f owned nodes / %.1f elements per tile, LDS <= %d bytes, "
               "Gauss-point redundancy %.3f\n", c->tileF.ok ? "ok" : "not built", tsT.ntile, tsT.ntile ? (double)nnode / tsT.ntile : 0.0,
@@ -1277,9 +1299,10 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   if (tile_fset) {                                     // GET_INT_VECTOR pass of the tile kernel: its own, larger tiles
     P.tinfo = c->tileF.tinfo; P.tnodes = c->tileF.tnodes; P.telems = c->tileF.telems; P.tconn = c->tileF.tconn;
     P.tpairs = c->tileF.tpairs; P.tents = c->tileF.tents; P.ntile3 = c->tileF.ntile; P.tile_lds = c->tileF.lds;
-    P.tile_block = c->tileF.block; P.tile_sym = 0; P.tile_stage = 0; P.tile_split = 0;
+    P.tile_block = c->tileF.block; P.tile_sym = 0; P.tile_stage = 0; P.tile_split = 0; P.tn_stride = c->tn_strideF;
   }
   if (emat) {                                          // element-matrix kernel: no atomics, so it also serves FA_DETERMINISTIC
+    P.tn_stride = 0;
     path = (emat == &c->fvec) ? fa::PATH_FVEC : fa::PATH_EMAT;
     P.eslot = emat->eslot; P.nval = emat->nval; P.fvec_val = emat->lpe;
     P.tinfo = emat->tinfo; P.tnodes = emat->tnodes; P.telems = emat->telems; P.tconn = emat->tconn;

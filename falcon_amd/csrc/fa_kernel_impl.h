@@ -1584,6 +1584,9 @@ __device__ __forceinline__ void swap_rec(const IpRec<SH, FAM, KEEP>& m, IpRec<SH
                                   read-modify-write stream-out.  Measured slower on cfg3 (6.14 against 5.6 ms): the reads sit in
                                   front of the gathers instead of behind the arithmetic, and a barrier waits for them. */
 #endif
+#ifndef FA_PAIR_EARLY_GATHER
+#define FA_PAIR_EARLY_GATHER 1
+#endif
 #ifndef FA_PAIR_ACC_LDSTAB
 #define FA_PAIR_ACC_LDSTAB 1   /* ... with the shape tables from the LDS copy, like the overwrite kernel */
 #endif
@@ -1640,6 +1643,45 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
 #pragma unroll
     for (int q = 0; q < LS / 4; q++) { const int4 v = rp4[q]; rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w; }
   }
+  RowBlock<SH, WANT_K, PF, KEEP> R;
+  int32_t cn[NPE];
+  int la = 0, aloc = 0, rs0 = 0, nnb = 0, half = 0;
+  int64_t e = 0;
+  uint32_t fl = 0;
+  bool owner = false;
+  uint8_t ps[NPE];
+  double err_acc = 0.0;
+  double H0v[HALF];
+  ElemData<SH, PF> E;
+#pragma unroll
+  for (int k = 0; k < HALF; k++) H0v[k] = 0.0;
+  // the gathers only need the lane record: FA_PAIR_EARLY_GATHER issues them in front of the image initialisation and its
+  // barrier, so that their round trip runs while the image is zeroed (which itself waits for the tile descriptor)
+  auto decode_and_gather = [&] {
+    e = rec[0] / NPE; la = rec[0] - (int)e * NPE;
+#pragma unroll
+    for (int b = 0; b < NPE; b++) cn[b] = rec[1 + b];
+    const uint32_t w0 = (uint32_t)rec[1 + NPE];
+    rs0 = (int)(w0 & 0xFFFFu); aloc = (int)((w0 >> 16) & 0xFFu); nnb = (int)(w0 >> 24);
+#pragma unroll
+    for (int b = 0; b < NPE; b++) ps[b] = (uint8_t)((uint32_t)rec[2 + NPE + (b >> 2)] >> (8 * (b & 3)));
+    fl = (uint32_t)rec[LS - 1];
+    owner = fl & 1u;
+    half = (fl >> 1) & 1;
+    if constexpr (PF) {
+      if (SP::model(P) == 1 || SP::model(P) >= 4) {
+#pragma unroll
+        for (int k = 0; k < HALF; k++) H0v[k] = P.hist_pre[e * NIP + half * HALF + k];
+      }
+    }
+    gather_elem<SH, PF, SP>(P, cn, E);
+  };
+  // (padded records: idle lanes hold a zero record, i.e. element 0 / node 0 -- a harmless gather --, so nobody waits for
+  //  the descriptor's lane count either)
+  // Measured on MI355X (round 3): cfg3 u-phi overwrite 4.52 -> 4.27 ms, MiehePhase 5.35 -> 5.21; with off-diagonal blocks
+  // the longer live ranges spill (4.56 -> 5.74 ms) and the elastic kernel loses 2 %, so those keep the old order.
+  const bool early = FA_PAIR_EARLY_GATHER && !ACC && !KEEP && PF && P.rec_padded;
+  if (early) decode_and_gather();
   if constexpr (ACC) {                                 // FA_ACCUMULATE: the image starts as the caller's K / f (stream_in16)
     if constexpr (WANT_K) {
       if ((((uintptr_t)P.K) & 15) == 0) stream_in16<kBlock>(P.K + base, sK, len, odd);
@@ -1653,34 +1695,8 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
   }
   __syncthreads();                                     // image initialised: from here every wave adds as soon as it has computed
 
-  RowBlock<SH, WANT_K, PF, KEEP> R;
-  int32_t cn[NPE];
-  int la = 0, aloc = 0, rs0 = 0, nnb = 0;
-  bool owner = false;
-  uint8_t ps[NPE];
-  double err_acc = 0.0;
   if (active) {
-    const int64_t e = rec[0] / NPE; la = rec[0] - (int)e * NPE;
-#pragma unroll
-    for (int b = 0; b < NPE; b++) cn[b] = rec[1 + b];
-    const uint32_t w0 = (uint32_t)rec[1 + NPE];
-    rs0 = (int)(w0 & 0xFFFFu); aloc = (int)((w0 >> 16) & 0xFFu); nnb = (int)(w0 >> 24);
-#pragma unroll
-    for (int b = 0; b < NPE; b++) ps[b] = (uint8_t)((uint32_t)rec[2 + NPE + (b >> 2)] >> (8 * (b & 3)));
-    const uint32_t fl = (uint32_t)rec[LS - 1];
-    owner = fl & 1u;
-    const int half = (fl >> 1) & 1;
-    double H0v[HALF];
-#pragma unroll
-    for (int k = 0; k < HALF; k++) H0v[k] = 0.0;
-    if constexpr (PF) {
-      if (SP::model(P) == 1 || SP::model(P) >= 4) {
-#pragma unroll
-        for (int k = 0; k < HALF; k++) H0v[k] = P.hist_pre[e * NIP + half * HALF + k];
-      }
-    }
-    ElemData<SH, PF> E;
-    gather_elem<SH, PF, SP>(P, cn, E);
+    if (!early) decode_and_gather();
 #ifdef FA_TRACE
     if (E.x[0][0] + E.u[3][1] + H0v[0] == 1.234e300) err_acc = 1.0;     // wait for the gathers
     tr[1] = __builtin_readcyclecounter();

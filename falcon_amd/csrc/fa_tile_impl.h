@@ -67,6 +67,23 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   if (tile0 >= P.ntile3) return;
   const int tile = P.tile_list ? P.tile_list[tile0] : tile0;   // interface / interior part of a pass (fa_set_interface)
   const int32_t* __restrict__ ti = P.tinfo + (int64_t)tile * kTileInfo;
+  // Node lists padded to a fixed stride per tile (P.tn_stride > 0): the address of a lane's first tile node depends on the
+  // tile index only, so its id and then its coordinates / state / row offsets are requested before the descriptor has
+  // arrived -- the staging chain descriptor -> node list -> nodal data loses one of its three memory round trips.
+  // (Idle slots of the padded list hold node 0: a harmless read.)
+  constexpr int NDOF0 = (FAM != FAM_LE) ? SH::RANK + 1 : SH::RANK;
+  const bool pre = P.tn_stride > 0;
+  int64_t n_pre = 0;
+  double pre_x[SH::RANK], pre_u[NDOF0];
+  long long pre_b0 = 0, pre_b1 = 0;
+  if (pre) {
+    n_pre = P.tnodes[(int64_t)tile * P.tn_stride + ((int)threadIdx.x < P.tn_stride ? (int)threadIdx.x : 0)];
+#pragma unroll
+    for (int d = 0; d < SH::RANK; d++) pre_x[d] = P.coords[n_pre * SH::RANK + d];
+#pragma unroll
+    for (int d = 0; d < NDOF0; d++) pre_u[d] = P.state[n_pre * NDOF0 + d];
+    if constexpr (WANT_K) { pre_b0 = P.row_ptr[n_pre * NDOF0]; pre_b1 = P.row_ptr[n_pre * NDOF0 + 1]; }
+  }
   const int node_off = ti[0], n_all = ti[1], n_own = ti[2], elem_off = ti[3], n_el = ti[4];
   const int pair_off = ti[5], n_pairs = ti[6], ent_off = ti[7];
 
@@ -87,23 +104,35 @@ __global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
   const double* tabW = sTab + NIP * NPE * (1 + RANK);
 
   // ---- phase 0: stage ----
-  for (int i = tid; i < n_all; i += BLK) {
+  auto stage_ext = [&](int i, int64_t n) {
+    if constexpr (PF) {
+      const int64_t dp = n * NDOF + RANK;
+      if (SP::model(P) == 2 || SP::model(P) == 3) { sExt[2 * i] = P.state0[dp]; sExt[2 * i + 1] = P.stateX[dp]; }
+      else if ((SP::model(P) == 5 || SP::model(P) == 6)) { sExt[2 * i] = 0.0; sExt[2 * i + 1] = P.stateX[dp]; }
+    }
+  };
+  if (pre && tid < n_all) {                             // the values requested in front of the descriptor
+    double* nd = sNod + tid * NODW;
+#pragma unroll
+    for (int d = 0; d < RANK; d++) { nd[d] = pre_x[d]; nd[RANK + d] = pre_u[d]; }
+    if constexpr (PF) nd[2 * RANK] = pre_u[RANK];
+    stage_ext(tid, n_pre);
+  }
+  for (int i = pre ? tid + BLK : tid; i < n_all; i += BLK) {
     const int64_t n = P.tnodes[node_off + i];
     double* nd = sNod + i * NODW;
 #pragma unroll
     for (int d = 0; d < RANK; d++) { nd[d] = P.coords[n * RANK + d]; nd[RANK + d] = P.state[n * NDOF + d]; }
-    if constexpr (PF) {
-      const int64_t dp = n * NDOF + RANK;
-      nd[2 * RANK] = P.state[dp];
-      if (SP::model(P) == 2 || SP::model(P) == 3) { sExt[2 * i] = P.state0[dp]; sExt[2 * i + 1] = P.stateX[dp]; }
-      else if ((SP::model(P) == 5 || SP::model(P) == 6)) { sExt[2 * i] = 0.0; sExt[2 * i + 1] = P.stateX[dp]; }
-    }
+    if constexpr (PF) nd[2 * RANK] = P.state[n * NDOF + RANK];
+    stage_ext(i, n);
   }
   for (int i = tid; i < n_f * NDOF; i += BLK) sF[i] = 0.0;
-  for (int i = tid; i < n_rows; i += BLK) {
+  const int cnt0 = P.cnt[0];
+  if (WANT_K && pre && tid < n_rows) { sRow[tid] = pre_b0; sDeg[tid] = (cnt0 > 0) ? (int)((pre_b1 - pre_b0) / cnt0) : 0; }
+  for (int i = (WANT_K && pre) ? tid + BLK : tid; i < n_rows; i += BLK) {
     const int64_t r0 = (int64_t)P.tnodes[node_off + i] * NDOF;
     const long long b0 = P.row_ptr[r0], b1 = P.row_ptr[r0 + 1];
-    sRow[i] = b0; sDeg[i] = (P.cnt[0] > 0) ? (int)((b1 - b0) / P.cnt[0]) : 0;
+    sRow[i] = b0; sDeg[i] = (cnt0 > 0) ? (int)((b1 - b0) / cnt0) : 0;
   }
   for (int i = tid; i < TABN; i += BLK) sTab[i] = P.tab[i];
   for (int i = tid; i < n_el * NPE; i += BLK) sConn[i] = P.tconn[(int64_t)elem_off * NPE + i];
