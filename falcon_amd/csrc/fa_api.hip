@@ -346,6 +346,7 @@ struct TileDev {
   bool ok = false;
   int ntile = 0, lds = 0, lpe = 1, block = 256;
   int lds_alt = 0;                                              // force-vector tiles: LDS bytes with one f row per owned node (atomic form)
+  int tn_stride = 0, te_stride = 0;       // node / element lists padded to a fixed stride per tile (0: packed)
   int conn_stride = 0, maxn = 0, maxe = 0, plds = 0, pgrid = 0;   // persistent form: staging capacities, LDS bytes, grid
   bool persistent = false;
   double redundancy = 0.0;
@@ -436,6 +437,38 @@ static int pad_tile_nodes(fa::TileSet& ts) {
     ti[0] = t * stride;
   }
   ts.tnodes.swap(padded);
+  if (!ts.nval.empty()) {                               // force-vector tiles: the valences run parallel to the node lists
+    std::vector<uint32_t> nv((size_t)ts.ntile * stride, 0);
+    size_t old_off = 0;
+    for (int t = 0; t < ts.ntile; t++) {
+      const int n_all = ts.tinfo[(size_t)t * fa::kTileInfo + 1];
+      std::copy(ts.nval.begin() + old_off, ts.nval.begin() + old_off + n_all, nv.begin() + (size_t)t * stride);
+      old_off += (size_t)n_all;
+    }
+    ts.nval.swap(nv);
+  }
+  return stride;
+}
+
+// The same for the element lists of the force-vector tiles (element words, rank words, local connectivity): a lane's
+// element word and with it the element's history are requested without waiting for the descriptor.
+static int pad_tile_elems(fa::TileSet& ts, int esw, int cs) {
+  int mx = 0;
+  for (int t = 0; t < ts.ntile; t++) mx = std::max(mx, ts.tinfo[(size_t)t * fa::kTileInfo + 4]);
+  if (ts.ntile == 0 || mx > 1024) return 0;
+  const int stride = (mx + 15) & ~15;
+  std::vector<int32_t> te((size_t)ts.ntile * stride, 0);
+  std::vector<uint32_t> es((size_t)ts.ntile * stride * esw, 0);
+  std::vector<uint16_t> tc((size_t)ts.ntile * stride * cs, 0);
+  for (int t = 0; t < ts.ntile; t++) {
+    int32_t* ti = ts.tinfo.data() + (size_t)t * fa::kTileInfo;
+    const size_t o = (size_t)ti[3], n = (size_t)ti[4], d = (size_t)t * stride;
+    std::copy(ts.telems.begin() + o, ts.telems.begin() + o + n, te.begin() + d);
+    std::copy(ts.eslot.begin() + o * esw, ts.eslot.begin() + (o + n) * esw, es.begin() + d * esw);
+    std::copy(ts.tconn.begin() + o * cs, ts.tconn.begin() + (o + n) * cs, tc.begin() + d * cs);
+    ti[3] = (int32_t)d;
+  }
+  ts.telems.swap(te); ts.eslot.swap(es); ts.tconn.swap(tc);
   return stride;
 }
 
@@ -1041,6 +1074,11 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       if (c->fvec.ok) {
         c->fvec.ntile = tsV.ntile; c->fvec.lds = tsV.lds_bytes; c->fvec.lds_alt = tsV.lds_bytes_alt; c->fvec.redundancy = tsV.point_redundancy; c->fvec.lpe = maxval;
         c->fvec.conn_stride = tsV.conn_stride;
+        if (dbg.pad_tnodes >= 0 ? dbg.pad_tnodes != 0 : true) {
+          c->fvec.tn_stride = pad_tile_nodes(tsV);
+          c->fvec.te_stride = c->fvec.tn_stride ? pad_tile_elems(tsV, (npe + 3) / 4, tsV.conn_stride) : 0;
+          if (!c->fvec.te_stride) c->fvec.tn_stride = 0;    // the kernel takes both or neither
+        }
         // persistent LDS-DMA form: PhaseFracture / MicroPhaseFracture / LinearElasticity, workgroups of 192 or 256
         const bool model_ok = p->model == FA_LINEAR_ELASTICITY || p->model == FA_PHASE_FRACTURE || p->model == FA_MICRO_PHASE_FRACTURE;
         if (model_ok && (dbg.persist > 0) && (c->fvec.block == 192 || c->fvec.block == 256)) {
@@ -1302,7 +1340,7 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
     P.tile_block = c->tileF.block; P.tile_sym = 0; P.tile_stage = 0; P.tile_split = 0; P.tn_stride = c->tn_strideF;
   }
   if (emat) {                                          // element-matrix kernel: no atomics, so it also serves FA_DETERMINISTIC
-    P.tn_stride = 0;
+    P.tn_stride = emat->tn_stride; P.te_stride = emat->te_stride;
     path = (emat == &c->fvec) ? fa::PATH_FVEC : fa::PATH_EMAT;
     P.eslot = emat->eslot; P.nval = emat->nval; P.fvec_val = emat->lpe;
     P.tinfo = emat->tinfo; P.tnodes = emat->tnodes; P.telems = emat->telems; P.tconn = emat->tconn;

@@ -515,6 +515,31 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
   if (tile0 >= P.ntile3) return;
   const int tile = P.tile_list ? P.tile_list[tile0] : tile0;   // interface / interior part of a pass (fa_set_interface)
   const int32_t* __restrict__ ti = P.tinfo + (int64_t)tile * kTileInfo;
+  // Lists padded to a fixed stride per tile (P.tn_stride, P.te_stride > 0): the lane's first tile node and element are
+  // addressed from the tile index alone, so their ids -- and then the nodal data and the element's history -- are requested
+  // before the descriptor has arrived: two memory round trips in front of the barrier instead of three.  (Idle slots
+  // hold node 0 / element 0: harmless reads.)
+  const bool pre = P.tn_stride > 0;
+  int64_t n_pre = 0;
+  uint32_t ew_pre = 0, es_pre[(NPE + 3) / 4], nv_pre = 0;
+  double pre_x[RANK], pre_u[NDOF], pre_H[NIP];
+  if (pre) {
+    const int64_t pn = (int64_t)tile * P.tn_stride + (tid < P.tn_stride ? tid : 0);
+    const int64_t pe = (int64_t)tile * P.te_stride + (tid < P.te_stride ? tid : 0);
+    n_pre = P.tnodes[pn]; nv_pre = P.nval[pn];
+    ew_pre = (uint32_t)P.telems[pe];
+#pragma unroll
+    for (int q = 0; q < (NPE + 3) / 4; q++) es_pre[q] = P.eslot[pe * ((NPE + 3) / 4) + q];
+#pragma unroll
+    for (int d = 0; d < RANK; d++) pre_x[d] = P.coords[n_pre * RANK + d];
+#pragma unroll
+    for (int d = 0; d < NDOF; d++) pre_u[d] = P.state[n_pre * NDOF + d];
+    if (PF && (SP::model(P) == 1 || SP::model(P) >= 4)) {
+      const int64_t e = (int64_t)(ew_pre & 0x7FFFFFFFu);
+#pragma unroll
+      for (int k = 0; k < NIP; k++) pre_H[k] = P.hist_pre[e * NIP + k];
+    }
+  }
   const int node_off = ti[0], n_all = ti[1], n_own = ti[2], elem_off = ti[3], n_el = ti[4];
   const int V = P.fvec_val;                            // buffer rows per owned node (largest valence of the mesh)
 
@@ -539,22 +564,39 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
 #pragma unroll
   for (int q = 0; q < EW; q++) es0[q] = 0;
   if (tid < n_el) {
-    ew0 = (uint32_t)P.telems[elem_off + tid];
+    if (pre) {
+      ew0 = ew_pre;
 #pragma unroll
-    for (int q = 0; q < EW; q++) es0[q] = P.eslot[(int64_t)(elem_off + tid) * EW + q];
+      for (int q = 0; q < EW; q++) es0[q] = es_pre[q];
+    } else {
+      ew0 = (uint32_t)P.telems[elem_off + tid];
+#pragma unroll
+      for (int q = 0; q < EW; q++) es0[q] = P.eslot[(int64_t)(elem_off + tid) * EW + q];
+    }
   }
-  for (int i = tid; i < n_all; i += BLK) {
+  auto stage_ext = [&](int i, int64_t n) {
+    if constexpr (PF) {
+      const int64_t dp = n * NDOF + RANK;
+      if (SP::model(P) == 2 || SP::model(P) == 3) { sExt[2 * i] = P.state0[dp]; sExt[2 * i + 1] = P.stateX[dp]; }
+      else if ((SP::model(P) == 5 || SP::model(P) == 6)) { sExt[2 * i] = 0.0; sExt[2 * i + 1] = P.stateX[dp]; }
+    }
+  };
+  if (pre && tid < n_all) {
+    if (tid < n_own) { sNode[tid] = (int)n_pre; sVal[tid] = (uint8_t)nv_pre; }
+    double* nd = sNod + tid * NODW;
+#pragma unroll
+    for (int d = 0; d < RANK; d++) { nd[d] = pre_x[d]; nd[RANK + d] = pre_u[d]; }
+    if constexpr (PF) nd[2 * RANK] = pre_u[RANK];
+    stage_ext(tid, n_pre);
+  }
+  for (int i = pre ? tid + BLK : tid; i < n_all; i += BLK) {
     const int64_t n = P.tnodes[node_off + i];
     if (i < n_own) { sNode[i] = (int)n; sVal[i] = (uint8_t)P.nval[node_off + i]; }
     double* nd = sNod + i * NODW;
 #pragma unroll
     for (int d = 0; d < RANK; d++) { nd[d] = P.coords[n * RANK + d]; nd[RANK + d] = P.state[n * NDOF + d]; }
-    if constexpr (PF) {
-      const int64_t dp = n * NDOF + RANK;
-      nd[2 * RANK] = P.state[dp];
-      if (SP::model(P) == 2 || SP::model(P) == 3) { sExt[2 * i] = P.state0[dp]; sExt[2 * i + 1] = P.stateX[dp]; }
-      else if ((SP::model(P) == 5 || SP::model(P) == 6)) { sExt[2 * i] = 0.0; sExt[2 * i + 1] = P.stateX[dp]; }
-    }
+    if constexpr (PF) nd[2 * RANK] = P.state[n * NDOF + RANK];
+    stage_ext(i, n);
   }
   for (int i = tid; i < n_el * CS; i += BLK) sConn[i] = P.tconn[(int64_t)elem_off * CS + i];
   if (atom) for (int i = tid; i < n_own * NDOF; i += BLK) sBuf[i] = 0.0;
@@ -563,9 +605,14 @@ __global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P
 #pragma unroll
   for (int k = 0; k < NIP; k++) H0v[k] = 0.0;
   if (hist_model && tid < n_el) {
-    const int64_t e = (int64_t)(ew0 & 0x7FFFFFFFu);
+    if (pre) {
 #pragma unroll
-    for (int k = 0; k < NIP; k++) H0v[k] = P.hist_pre[e * NIP + k];
+      for (int k = 0; k < NIP; k++) H0v[k] = pre_H[k];
+    } else {
+      const int64_t e = (int64_t)(ew0 & 0x7FFFFFFFu);
+#pragma unroll
+      for (int k = 0; k < NIP; k++) H0v[k] = P.hist_pre[e * NIP + k];
+    }
   }
   __syncthreads();
 

@@ -1680,7 +1680,7 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
   //  the descriptor's lane count either)
   // Measured on MI355X (round 3): cfg3 u-phi overwrite 4.52 -> 4.27 ms, MiehePhase 5.35 -> 5.21; with off-diagonal blocks
   // the longer live ranges spill (4.56 -> 5.74 ms) and the elastic kernel loses 2 %, so those keep the old order.
-  const bool early = FA_PAIR_EARLY_GATHER && !ACC && !KEEP && PF && P.rec_padded;
+  const bool early = FA_PAIR_EARLY_GATHER && !KEEP && PF && P.rec_padded;
   if (early) decode_and_gather();
   if constexpr (ACC) {                                 // FA_ACCUMULATE: the image starts as the caller's K / f (stream_in16)
     if constexpr (WANT_K) {
