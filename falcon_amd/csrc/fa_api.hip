@@ -940,12 +940,16 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       // Hex20, general tangents in 3-D) get one 1024-thread workgroup with the whole LDS (Hex20 Gauss3^3 at 64^3: 8.8
       // against 10.9 ms)
       const int recw = fa::tile_rec_doubles(rank, c->fam, keepK, npe);
-      const bool big = rank == 3 && (dbg.tile_big >= 0 ? dbg.tile_big != 0 : fa::tile_slot_doubles(sh.nip, recw) >= fa::kTileBigSlot);
+      // Hex8 kernels that need more than 128 registers whatever the geometry (off-diagonal blocks kept: 147-154; GradientDamage:
+      // 202-206) run one 512-thread workgroup per CU anyway, so they take the whole LDS and larger boxes (round 3: cfg4 with
+      // keepOffDiags at 128^3 9.97 -> 7.10 ms, GradientDamage 12.4 -> 7.49 ms; boxes of 4 x 4 x 3 / 5 x 4 x 4 nodes 7.5 / 7.8 ms)
+      const bool heavy8 = p->shape == FA_HEX8_G2 && c->fam != fa::FAM_PF_MIEHE && (keepK || gd);
+      const bool big = rank == 3 && (dbg.tile_big >= 0 ? dbg.tile_big != 0 : (heavy8 || fa::tile_slot_doubles(sh.nip, recw) >= fa::kTileBigSlot));
       // FA_TILE_BIG=2: the big LDS budget with a 512-thread workgroup -- one workgroup per CU at two waves per SIMD, so the
       // kernel may use 256 registers (1024 threads pin it at 128: the general-tangent kernels then spill 0.5 KB per lane)
       // Default for the general-tangent family (MiehePhase, the micromorphic models): cfg4 / MiehePhase at 96^3 6.60 -> 5.14 ms.
       // Not for Hex20 elastic (5.71 against 4.96 ms at 64^3: no spills to lose there).
-      const bool big512 = big && (dbg.tile_big >= 0 ? dbg.tile_big == 2 : c->fam == fa::FAM_PF_MIEHE);
+      const bool big512 = big && (dbg.tile_big >= 0 ? dbg.tile_big == 2 : (c->fam == fa::FAM_PF_MIEHE || heavy8));
       P.tile_block = (big && !big512) ? fa::kTileBlockBig : fa::kTileBlock;
       // one lane per unordered node pair across tiles (TileOpts::sym_all) unless the lanes are in row order
       fa::TileOpts topt;
@@ -964,7 +968,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
         // Hex8: boxes of 3 x 3 x 3 nodes bring 4 x 4 x 4 = 64 elements = 512 (element, Gauss point) lanes, one full round of the
         // workgroup, at 2.4 evaluations per point; the Morton cut (4 x 4 x 2 does not fit the LDS budget) gave 21.7 nodes / 57
         // elements at 2.7 (cfg4 at 128^3: 5.45 -> 5.25 ms, GET_INT_VECTOR 2.30 -> 2.07 ms)
-        const int cellc = dbg.tile_cell >= 0 ? dbg.tile_cell : (p->shape == FA_HEX8_G2 ? 333 : 0);
+        const int cellc = dbg.tile_cell >= 0 ? dbg.tile_cell : (p->shape == FA_HEX8_G2 ? ((heavy8 && big512) ? 444 : 333) : 0);
         if (rank == 3 && cellc >= 111) { topt.cell[0] = cellc / 100; topt.cell[1] = (cellc / 10) % 10; topt.cell[2] = cellc % 10; }
       }
       int budget = big ? fa::kTileLdsBig : fa::kTileLds;
