@@ -944,7 +944,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       // 202-206) run one 512-thread workgroup per CU anyway, so they take the whole LDS and larger boxes (round 3: cfg4 with
       // keepOffDiags at 128^3 9.97 -> 7.10 ms, GradientDamage 12.4 -> 7.49 ms; boxes of 4 x 4 x 3 / 5 x 4 x 4 nodes 7.5 / 7.8 ms)
       const bool heavy8 = p->shape == FA_HEX8_G2 && c->fam != fa::FAM_PF_MIEHE && (keepK || gd);
-      const bool big = rank == 3 && (dbg.tile_big >= 0 ? dbg.tile_big != 0 : (heavy8 || fa::tile_slot_doubles(sh.nip, recw) >= fa::kTileBigSlot));
+      const bool big = (rank == 3 || dbg.tile_big == 2) && (dbg.tile_big >= 0 ? dbg.tile_big != 0 : (heavy8 || fa::tile_slot_doubles(sh.nip, recw) >= fa::kTileBigSlot));
       // FA_TILE_BIG=2: the big LDS budget with a 512-thread workgroup -- one workgroup per CU at two waves per SIMD, so the
       // kernel may use 256 registers (1024 threads pin it at 128: the general-tangent kernels then spill 0.5 KB per lane)
       // Default for the general-tangent family (MiehePhase, the micromorphic models): cfg4 / MiehePhase at 96^3 6.60 -> 5.14 ms.

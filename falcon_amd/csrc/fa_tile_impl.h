@@ -47,8 +47,21 @@ struct TileRec {                                        // offsets (doubles) ins
 // block instead of one per 32-byte chunk -- which costs registers the overwrite kernels must not pay (as a runtime branch
 // it slowed them from 5.3 to 7.7 ms on cfg4 at 128^3), hence a compile-time variant.  ACC = false serves FA_OVERWRITE and,
 // for the GET_INT_VECTOR passes, both modes.
+// The 2-D general-tangent instantiations (129-136 VGPRs) sit a few registers above the 128 that two 512-thread workgroups
+// per CU need, and ran one workgroup per CU because of them.  FA_TILE_CAP asks the compiler for four waves per SIMD there
+// (second launch-bounds argument = waves per execution unit): 12-28 bytes of scratch per lane, measured Quad8 / MiehePhase
+// 2.98 -> 2.45 ms, Triangle6 3.21 -> 2.15, Triangle3 Gauss3 3.46 -> 2.45 (the whole LDS for one workgroup instead: 2.91 /
+// 2.73 / 3.18).  Not for the 3-D elastic kernels (Hex20 with Hooke, 134-136 VGPRs): capped, Hex20 Gauss2^3 at 64^3 went
+// from 3.6 to 3.86 ms -- their grouped pair lanes lose more to the spills than the second workgroup brings.
+#ifndef FA_TILE_CAP
+#define FA_TILE_CAP 1
+#endif
+template <class SH, int FAM, int BLK>
+constexpr int tile_min_waves() {
+  return (FA_TILE_CAP && BLK == 512 && SH::RANK == 2 && FAM == FAM_PF_MIEHE) ? 4 : 1;
+}
 template <class SH, int FAM, bool WANT_K, bool KEEP, class SP, int BLK, bool ACC = false>
-__global__ __launch_bounds__(BLK) void assemble_tiles(const Params P) {
+__global__ __launch_bounds__(BLK, (tile_min_waves<SH, FAM, BLK>())) void assemble_tiles(const Params P) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, S = SH::S, STR = SH::STR;
   constexpr bool PF = (FAM != FAM_LE);
   constexpr int NDOF = PF ? RANK + 1 : RANK;
