@@ -498,8 +498,17 @@ __global__ __launch_bounds__(BLK) FA_EMAT_ATTR void assemble_emat(const Params P
 #ifndef FA_FVEC_ATTR
 #define FA_FVEC_ATTR
 #endif
+// Instantiations a few registers above an occupancy step (Quad4 with a general tangent: 173, Triangle3 GradientDamage: 171;
+// the LDS of a tile leaves room for three waves per SIMD, 168 registers) are asked for that step: FA_FVEC_CAP.
+#ifndef FA_FVEC_CAP
+#define FA_FVEC_CAP 1
+#endif
+template <class SH, int FAM, class SP>
+constexpr int fvec_min_waves() {
+  return (FA_FVEC_CAP && SH::RANK == 2 && ((FAM == FAM_PF_MIEHE && SH::NPE == 4) || (SP::gd && SH::NPE == 3))) ? 3 : 1;
+}
 template <class SH, int FAM, class SP, int BLK>
-__global__ __launch_bounds__(BLK) FA_FVEC_ATTR void assemble_fvec(const Params P) {
+__global__ __launch_bounds__(BLK, (fvec_min_waves<SH, FAM, SP>())) FA_FVEC_ATTR void assemble_fvec(const Params P) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP;
   constexpr bool PF = (FAM != FAM_LE);
   constexpr int NDOF = PF ? RANK + 1 : RANK;
