@@ -505,6 +505,7 @@ __global__ __launch_bounds__(BLK) FA_EMAT_ATTR void assemble_emat(const Params P
 #endif
 template <class SH, int FAM, class SP>
 constexpr int fvec_min_waves() {
+  if (FA_FVEC_CAP && SH::RANK == 3) return 2;
   return (FA_FVEC_CAP && SH::RANK == 2 && ((FAM == FAM_PF_MIEHE && SH::NPE == 4) || (SP::gd && SH::NPE == 3))) ? 3 : 1;
 }
 template <class SH, int FAM, class SP, int BLK>
