@@ -80,6 +80,7 @@ struct DebugOptions {
   bool use_patch = false; // FA_USE_PATCH=1: experimental patch kernel
   int  patch_lds = 0;     // FA_PATCH_LDS=n: doubles of LDS for its CSR image
   bool verbose = false;   // FA_VERBOSE=1: tiling statistics on stderr
+  int  micro_mask = 0;    // FA_MICRO_AMOR_MASK=1: Micro + AmorPhase, the pre-pass classifies EVERY Gauss point (see fa_create)
   static DebugOptions from_env() {
     DebugOptions o;
     auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
@@ -89,7 +90,7 @@ struct DebugOptions {
     o.persist = geti("FA_PERSIST", -1); o.tile_cell = geti("FA_TILE_CELL", -1);
     o.no_pair = getenv("FA_NO_PAIR") != nullptr; o.pair_3d = getenv("FA_PAIR_3D") != nullptr;
     o.pad_rec = geti("FA_PAD_REC", 1); o.pad_tnodes = geti("FA_PAD_TNODES", -1); o.use_patch = getenv("FA_USE_PATCH") != nullptr;
-    o.patch_lds = geti("FA_PATCH_LDS", 0); o.verbose = getenv("FA_VERBOSE") != nullptr;
+    o.micro_mask = geti("FA_MICRO_AMOR_MASK", 0); o.patch_lds = geti("FA_PATCH_LDS", 0); o.verbose = getenv("FA_VERBOSE") != nullptr;
     return o;
   }
 };
@@ -1175,7 +1176,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   c->max_parts = std::max(c->max_parts, std::max(std::max(c->ematK.ntile, c->ematF.ntile), std::max(c->fvec.ntile, c->tileF.ntile)));
   if (p->model >= FA_MICRO_PHASE_FRACTURE && p->model <= FA_MICRO_PHASE_FRACTURE_EXTIT && p->material == FA_AMOR_PHASE) {
     HIP_TRY(hipMalloc((void**)&c->d_first_comp, sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void**)&c->d_comp_mask, sizeof(uint32_t) * std::max<int64_t>(nel, 1)));
+    if (c->dbg.micro_mask) HIP_TRY(hipMalloc((void**)&c->d_comp_mask, sizeof(uint32_t) * std::max<int64_t>(nel, 1)));
     if (dbg.verbose)
       fprintf(stderr, "[falcon_assemble] MicroPhaseFracture* + AmorPhase: stiffN of a tension point is K PVol once the element loop has "
               "passed a compression point and ZERO before (the reference reads an uninitialised array there); K and f_int therefore "
@@ -1419,7 +1420,7 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
     const int rc0 = (c->rank == 2) ? fa::launch_first_comp_2d(P, c->npe, c->nip, c->d_first_comp, c->d_comp_mask, (void*)st)
                                    : fa::launch_first_comp_3d(P, c->npe, c->nip, c->d_first_comp, c->d_comp_mask, (void*)st);
     if (rc0 != 0) return fail(FA_ERR_HIP, "first_comp_kernel launch failed: %s", hipGetErrorString((hipError_t)rc0));
-    P.first_comp = c->d_first_comp; P.comp_mask = c->d_comp_mask;
+    P.first_comp = c->d_first_comp; P.comp_mask = c->d_comp_mask;   // the mask: FA_MICRO_AMOR_MASK=1 only
   }
   P.stale_hits = c->d_stale;
   if (c->d_stale) HIP_TRY(hipMemsetAsync(c->d_stale, 0, sizeof(unsigned long long), st));

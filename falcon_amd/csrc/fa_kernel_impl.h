@@ -657,9 +657,18 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
           // (MicroPhaseFractureModel.cpp:535), so a point in tension finds K PVol once the serial loop has passed a
           // compression point (first_comp_kernel) and the array's initial contents -- zero assumed, as in the checker -- before.
           const double tr = (RANK == 3) ? (eps[0] + eps[1] + eps[RANK - 1]) : (eps[0] + eps[1] + 0.0);
-          // tension / compression of the point as the pre-pass classified it (one decision per call for every kernel path:
-          // this kernel's own tr may differ from the pre-pass's in the last bits and land on the other side of zero)
-          const bool comp = (P.comp_mask[ipoint / SH::NIP] >> (int)(ipoint % SH::NIP)) & 1u;
+          // The one call-wide decision -- which point is the first in compression -- is the pre-pass's (first_comp_kernel), and
+          // this kernel's own tr, whose last bits differ from path to path (unrolled sums, sym(F J^-1), ...), is overruled
+          // where it could contradict it: every point before the first is in tension, the first one is in compression.
+          // Behind it the order no longer matters (kn = K either way) and the point's own sign decides its own branch, as in
+          // the plain AmorPhase kernels.
+          const unsigned long long first = *P.first_comp;
+          // FA_MICRO_AMOR_MASK=1 (P.comp_mask): the pre-pass classifies every point, so the kernel paths also agree with each
+          // other on points whose tr is rounding noise (where the tangent jumps by O(K) and no two summation orders need
+          // agree -- as in the plain AmorPhase kernels): a full sweep of the pre-pass and one more load per point, cfg3
+          // mesh 5.2 -> 6.8 ms, hence opt-in.
+          const bool comp = P.comp_mask ? (((P.comp_mask[ipoint / SH::NIP] >> (int)(ipoint % SH::NIP)) & 1u) != 0)
+                          : (((unsigned long long)ipoint < first) ? false : (((unsigned long long)ipoint == first) ? true : (tr <= 0.0)));
           double dd = 2.0 * P.G * (2.0 / 3.0), od = 2.0 * P.G * (-1.0 / 3.0);
           const double sh = 2.0 * P.G * 0.5;
           if (!comp) { dd += P.Kb; od += P.Kb; }
@@ -675,7 +684,7 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
           }
           Psi = 0.5 * psi2;
           const double g = gfun(Psi, sp);
-          const double kn = (comp || (unsigned long long)ipoint > *P.first_comp) ? P.Kb : 0.0;
+          const double kn = (comp || (unsigned long long)ipoint > first) ? P.Kb : 0.0;
           const double sn = kn * tr;
 #pragma unroll
           for (int i = 0; i < S; i++) {

@@ -1285,17 +1285,20 @@ __global__ __launch_bounds__(128) void arc_func_kernel(const Params P, int npe, 
 // MicroPhaseFracture* with AmorPhase: the reference's split material update writes stiffN only at Gauss points with
 // trace(strain) <= 0 (AmorPhaseMaterial.cpp:256-263) into an array that lives outside the model's element loop
 // (MicroPhaseFractureModel.cpp:535), so every later point of the serial loop in tension finds K PVol there.  One lane per
-// element: the sign of trace(strain) at each of its Gauss points goes into a bit mask (bit ip set: tr <= 0), and the
-// smallest serial index e * nip + ip of a compression point into `first` by a 64-bit atomic minimum.  The assembly
-// kernels -- whose strain arithmetic differs from path to path (unrolled sums, sym(F J^-1), ...) and could put a point
-// with tr of rounding size on the other side -- take the classification of every point from this mask, so ONE
-// computation decides tension / compression and the first compression point for the whole call.
+// element: the smallest serial index e * nip + ip of a Gauss point with tr <= 0 goes into `first` by a 64-bit atomic
+// minimum; elements behind the minimum found so far leave at once (workgroups start roughly in order), so the pass costs
+// a fraction of a sweep unless the whole mesh is in tension.  This is the ONE computation that decides the first
+// compression point of the call: the assembly kernels, whose strain arithmetic differs from path to path, take every
+// point before it as tension and the point itself as compression whatever the last bits of their own trace say
+// (ip_material, SpecMA).  `mask` (optional, nullptr in the product path): bit ip of mask[e] set when tr <= 0 at point ip --
+// with a mask no element may leave early.
 template <int RANK>
 __global__ __launch_bounds__(256) void first_comp_kernel(const Params P, int npe, int nip, unsigned long long* __restrict__ first,
                                                          uint32_t* __restrict__ mask) {
   constexpr int ND = RANK + 1;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= P.nel) return;
+  if (mask == nullptr && (unsigned long long)(e * nip) >= *(volatile unsigned long long*)first) return;
   auto dof = [&](int64_t node, int k) -> int64_t { return P.node_dofs ? P.node_dofs[node * ND + k] : node * ND + k; };
   const int32_t* cn = P.conn + e * npe;
   uint32_t m = 0;
@@ -1345,9 +1348,9 @@ __global__ __launch_bounds__(256) void first_comp_kernel(const Params P, int npe
       }
     }
     const double tr = (RANK == 3) ? (en[0] + en[1] + en[RANK - 1]) : (en[0] + en[1] + 0.0);
-    if (tr <= 0.0) m |= 1u << ip;
+    if (tr <= 0.0) { m |= 1u << ip; if (mask == nullptr) break; }
   }
-  mask[e] = m;
+  if (mask != nullptr) mask[e] = m;
   if (m != 0u) {
     const unsigned long long t = (unsigned long long)(e * nip + (__ffs((int)m) - 1));
     if (t < *(volatile unsigned long long*)first) atomicMin(first, t);

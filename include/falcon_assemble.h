@@ -42,7 +42,13 @@ enum { FA_LINEAR_ELASTICITY = 0, FA_PHASE_FRACTURE = 1, FA_PHASE_FRACTURE_EXT = 
                                       undefined there; this library ASSUMES ZERO.  Consequences the caller must know: K and
                                       f_int depend on the serial element numbering (through the first compression point of
                                       the call) and on the partition (every context / rank finds its own first compression
-                                      point), exactly as the reference's would.  FA_VERBOSE=1 prints this at fa_create. */
+                                      point), exactly as the reference's would.  FA_VERBOSE=1 prints this at fa_create.
+                                      The first compression point is found once per call by a pre-pass and every kernel
+                                      follows it (points before it are tension, the point itself compression, whatever the
+                                      last bits of a kernel's own trace say).  A point whose trace is rounding noise
+                                      elsewhere keeps the sign its kernel computes -- the tangent jumps by O(K) there in the
+                                      reference too; FA_MICRO_AMOR_MASK=1 at fa_create makes the pre-pass classify every
+                                      point (all kernel paths then agree on K as well; +30 % on the cfg3 mesh). */
        FA_MICRO_PHASE_FRACTURE_EXT = 5,   /* "MicroPhaseFractureExt", MicroPhaseFractureExtModel.cpp:523-952: g from
                                       the damage solved for the extrapolated micromorphic variable; the caller passes
                                       stateExt_ (:553-566) as state00; state0 / dt / dt0 are not read; penalty 6500 */

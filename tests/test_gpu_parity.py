@@ -550,11 +550,15 @@ def _shear_state(trace):
 
 @pytest.mark.parametrize("shape", [capi.QUAD4_G2, capi.HEX8_G2])
 def test_micro_amor_near_isochoric(shape):
-    """tension / compression of a point is decided ONCE per call, by the pre-pass, for every kernel path.
+    """the call-wide decision -- which Gauss point is the first in compression -- is made ONCE, by the
+    pre-pass, for every kernel path.
     (i) |tr| = 1e-9 -- tiny against the shear 2e-3 but far above rounding, so the checker classifies alike: every path
     against the checker at 1e-12.  (ii) tr = 0 up to rounding (simple shear on a distorted mesh): the sign of tr is
-    noise there and no two implementations need agree, but all device paths must agree WITH EACH OTHER, since they read
-    one classification (before, each kernel used the sign of its own strain arithmetic)."""
+    noise there and no two implementations need agree.  By default the device paths agree with each other on f_int and
+    the history (the stress does not see the sign of a vanishing trace); their tangents may differ at such points, as
+    those of the plain AmorPhase kernels do -- the tangent jumps by O(K) across tr = 0 in the reference itself.  With
+    FA_MICRO_AMOR_MASK=1 the pre-pass classifies every point and all paths agree on K as well."""
+    import os
     import torch
     run_micro(shape, capi.AMOR_PHASE, keep=1, state_mod=_shear_state(1e-9))
     run_micro(shape, capi.AMOR_PHASE, keep=0, want_K=False, state_mod=_shear_state(1e-9))
@@ -563,24 +567,31 @@ def test_micro_amor_near_isochoric(shape):
     coords, conn, st, kw, cfg = make_case(shape, capi.MICRO_PHASE_FRACTURE, capi.AMOR_PHASE, 0)
     kw["beta"] = 250.0
     st = _shear_state(0.0)(coords, conn, st.copy())
-    asm = capi.Assembler(shape, capi.MICRO_PHASE_FRACTURE, capi.AMOR_PHASE, coords, conn, **kw)
-    rp, _ = asm.pattern()
     dev = torch.device("cuda", 0)
     sd = torch.from_numpy(st).to(dev)
-    out = {}
-    for name, fl, wk in (("default", capi.OVERWRITE, True), ("ordered", capi.OVERWRITE | capi.DETERMINISTIC, True),
-                         ("generic", capi.OVERWRITE | capi.FORCE_GENERIC, True), ("force", capi.OVERWRITE, False)):
-        K = torch.zeros(asm.nnz, dtype=torch.float64, device=dev) if wk else None
-        f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
-        asm.assemble(sd, K, f, flags=fl)
-        torch.cuda.synchronize()
-        out[name] = (None if K is None else K.cpu().numpy(), f.cpu().numpy(), asm.get_history(1))
-    K0, f0, h0 = out["default"]
-    for name in ("ordered", "generic", "force"):
-        K, f, h = out[name]
-        if K is not None:
-            assert rel_rowmax_err(rp, K, K0) < TOL, name
-        assert vec_err(f, f0) < TOL and np.abs(h - h0).max() < TOL, name
+    for strict in (False, True):
+        if strict:
+            os.environ["FA_MICRO_AMOR_MASK"] = "1"
+        try:
+            asm = capi.Assembler(shape, capi.MICRO_PHASE_FRACTURE, capi.AMOR_PHASE, coords, conn, **kw)
+        finally:
+            os.environ.pop("FA_MICRO_AMOR_MASK", None)
+        rp, _ = asm.pattern()
+        out = {}
+        for name, fl, wk in (("default", capi.OVERWRITE, True), ("ordered", capi.OVERWRITE | capi.DETERMINISTIC, True),
+                             ("generic", capi.OVERWRITE | capi.FORCE_GENERIC, True), ("force", capi.OVERWRITE, False)):
+            K = torch.zeros(asm.nnz, dtype=torch.float64, device=dev) if wk else None
+            f = torch.zeros(asm.ndof, dtype=torch.float64, device=dev)
+            asm.assemble(sd, K, f, flags=fl)
+            torch.cuda.synchronize()
+            out[name] = (None if K is None else K.cpu().numpy(), f.cpu().numpy(), asm.get_history(1))
+        K0, f0, h0 = out["default"]
+        for name in ("ordered", "generic", "force"):
+            K, f, h = out[name]
+            if K is not None and strict:
+                assert rel_rowmax_err(rp, K, K0) < TOL, name
+            assert vec_err(f, f0) < TOL and np.abs(h - h0).max() < TOL, (name, strict)
+        asm.close()
 
 
 @pytest.mark.parametrize("model", [capi.MICRO_PHASE_FRACTURE_EXT, capi.MICRO_PHASE_FRACTURE_EXTIT])
