@@ -80,6 +80,7 @@ struct DebugOptions {
   bool use_patch = false; // FA_USE_PATCH=1: experimental patch kernel
   int  patch_lds = 0;     // FA_PATCH_LDS=n: doubles of LDS for its CSR image
   bool verbose = false;   // FA_VERBOSE=1: tiling statistics on stderr
+  int  pair_pers = -1;    // FA_PAIR_PERSIST=0|n: lane-pair kernel, GET_MATRIX0 passes: one workgroup per tile | n persistent workgroups (default: one per 16 tiles)
   int  micro_mask = 0;    // FA_MICRO_AMOR_MASK=1: Micro + AmorPhase, the pre-pass classifies EVERY Gauss point (see fa_create)
   static DebugOptions from_env() {
     DebugOptions o;
@@ -90,7 +91,7 @@ struct DebugOptions {
     o.persist = geti("FA_PERSIST", -1); o.tile_cell = geti("FA_TILE_CELL", -1);
     o.no_pair = getenv("FA_NO_PAIR") != nullptr; o.pair_3d = getenv("FA_PAIR_3D") != nullptr;
     o.pad_rec = geti("FA_PAD_REC", 1); o.pad_tnodes = geti("FA_PAD_TNODES", -1); o.use_patch = getenv("FA_USE_PATCH") != nullptr;
-    o.micro_mask = geti("FA_MICRO_AMOR_MASK", 0); o.patch_lds = geti("FA_PATCH_LDS", 0); o.verbose = getenv("FA_VERBOSE") != nullptr;
+    o.micro_mask = geti("FA_MICRO_AMOR_MASK", 0); o.pair_pers = geti("FA_PAIR_PERSIST", -1); o.patch_lds = geti("FA_PATCH_LDS", 0); o.verbose = getenv("FA_VERBOSE") != nullptr;
     return o;
   }
 };
@@ -850,6 +851,10 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       // records padded to one workgroup's worth per tile: a lane's record address depends on blockIdx only, so its
       // load does not wait for the tile descriptor
       P.rec_padded = dbg.pad_rec;
+      // persistent workgroups for the GET_MATRIX0 passes: every workgroup walks ~16 tiles and requests the lane records of the
+      // next one before it streams the current image out (cfg3: 4.27 -> 3.94 ms; 31 tiles each 3.96, 4 tiles 4.18, 496 tiles
+      // 4.18 -- few workgroups run in lockstep; meshes below 32 k tiles keep one workgroup per tile: 1000^2 0.303 against 0.317)
+      P.pair_pers = dbg.pair_pers >= 0 ? (dbg.pair_pers & ~7) : (nt >= 32768 ? (int)(((nt / 16) + 7) & ~7) : 0);
       if (P.rec_padded) { for (int64_t w = 0; w <= nt; w++) lane0[w] = w * kBlock; lanes_total = nt * kBlock; }
       lrec2.assign((size_t)(lanes_total + 2) * LS, 0);
       wginfo2.assign((size_t)nt * fa::kWgInfo, 0);

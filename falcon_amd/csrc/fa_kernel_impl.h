@@ -1596,6 +1596,9 @@ __device__ __forceinline__ void swap_rec(const IpRec<SH, FAM, KEEP>& m, IpRec<SH
 #ifndef FA_PAIR_EARLY_GATHER
 #define FA_PAIR_EARLY_GATHER 1
 #endif
+#ifndef FA_PAIR_PERS_GATHER
+#define FA_PAIR_PERS_GATHER 0
+#endif
 #ifndef FA_PAIR_ACC_LDSTAB
 #define FA_PAIR_ACC_LDSTAB 1   /* ... with the shape tables from the LDS copy, like the overwrite kernel */
 #endif
@@ -1603,7 +1606,12 @@ __device__ __forceinline__ void swap_rec(const IpRec<SH, FAM, KEEP>& m, IpRec<SH
 // candidates come from scalar loads and are picked with selects.  Measured on cfg3 / cfg2 (MI355X, round 2): the LDS
 // copy wins for the u-phi matrix pass in overwrite mode (4.55 against 4.89 ms), the selects win for the accumulate
 // mode (7.06 / 7.40), with off-diagonal blocks (4.51 / 4.95) and for the elastic model (2.21 / 2.32).
-template <class SH, int FAM, bool WANT_K, bool KEEP, class SP, bool LDSTAB, bool ACC = false>
+// PERS (P.pair_pers workgroups, each walking tiles bid, bid + grid, ...): the lane records of the NEXT tile are requested
+// before the image of the current one is streamed out and its gathers are issued right behind the stream-out, so the two
+// memory round trips in front of a tile's arithmetic run under the write-out of the tile before it.  Needs padded records
+// (the record address must not depend on the descriptor) and the early-gather order; the image itself is single-buffered
+// (a barrier separates the last read of the stream-out from the zero fill).
+template <class SH, int FAM, bool WANT_K, bool KEEP, class SP, bool LDSTAB, bool ACC = false, bool PERS = false>
 __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(const Params P) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, HALF = SH::NIP / 2, kBlock = SH::BLOCK, kLdsDoubles = SH::LDS;
   constexpr bool PF = (FAM != FAM_LE);
@@ -1627,31 +1635,21 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
     const const_dptr tN = (const_dptr)P.tab, tD = tN + NIP * NPE, tW = tN + NIP * NPE * (1 + RANK);
     sTabL[tid] = (q < NPE * RANK) ? tD[ipt * NPE * RANK + q] : ((q < NPE * (RANK + 1)) ? tN[ipt * NPE + (q - NPE * RANK)] : ((q == NPE * (RANK + 1)) ? tW[ipt] : 0.0));
   }
-  const int per = (int)gridDim.x >> 3;                 // XCD bands as in assemble_rows
-  const int tile0 = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  // XCD bands as in assemble_rows: virtual block v -> tile (v & 7) * per + (v >> 3), v = blockIdx.x (+ k * gridDim.x: PERS)
+  const int vtot = PERS ? ((P.ntile2 + 7) & ~7) : (int)gridDim.x;
+  const int per = vtot >> 3;
+  int vb = (int)blockIdx.x;
+  const int tile0 = (vb & 7) * per + (vb >> 3);
   if (tile0 >= P.ntile2) return;
-  const int tile = P.tile_list ? P.tile_list[tile0] : tile0;   // interface / interior part of a pass (fa_set_interface)
-  const int32_t* __restrict__ wi = P.wginfo2 + (int64_t)tile * kWgInfo;
+  int tile = P.tile_list ? P.tile_list[tile0] : tile0;   // interface / interior part of a pass (fa_set_interface)
   constexpr int LS = lrec_stride2(NPE);
   int32_t rec[LS];
-  if (P.rec_padded) {                                  // one workgroup's worth of records per tile: no wait for the descriptor
-    const int4* __restrict__ rp4 = (const int4*)(P.lrec2 + ((int64_t)tile * kBlock + tid) * LS);
+  auto load_rec_padded = [&](int tl) {
+    const int4* __restrict__ rp4 = (const int4*)(P.lrec2 + ((int64_t)tl * kBlock + tid) * LS);
 #pragma unroll
     for (int q = 0; q < LS / 4; q++) { const int4 v = rp4[q]; rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w; }
-  }
-  const int n0 = wi[0], n1 = wi[1], nlane = wi[3];
-  const int64_t t0 = ((int64_t)(uint32_t)wi[2]) | ((int64_t)wi[7] << 32);
-  const int64_t base = ((int64_t)(uint32_t)wi[4]) | ((int64_t)wi[5] << 32);
-  const int len = WANT_K ? wi[6] : 0;
-  const int odd = (int)(base & 1);                     // image shifted by one double when K + base is not 16-byte aligned
-  double* sK = sKbuf + odd;
-  const int nf = (n1 - n0) * NDOF;
-  const bool active = tid < nlane;                     // nlane is even: pairs are active together
-  if (!P.rec_padded) {
-    const int4* __restrict__ rp4 = (const int4*)(P.lrec2 + (t0 + (active ? tid : 0)) * LS);
-#pragma unroll
-    for (int q = 0; q < LS / 4; q++) { const int4 v = rp4[q]; rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w; }
-  }
+  };
+  if (P.rec_padded) load_rec_padded(tile);             // one workgroup's worth of records per tile: no wait for the descriptor
   RowBlock<SH, WANT_K, PF, KEEP> R;
   int32_t cn[NPE];
   int la = 0, aloc = 0, rs0 = 0, nnb = 0, half = 0;
@@ -1685,12 +1683,29 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
     }
     gather_elem<SH, PF, SP>(P, cn, E);
   };
+  bool gathered = false;                               // PERS: the gathers of this tile were issued under the last stream-out
+#pragma clang loop unroll(disable)
+  for (;;) {
+  const int32_t* __restrict__ wi = P.wginfo2 + (int64_t)tile * kWgInfo;
+  const int n0 = wi[0], n1 = wi[1], nlane = wi[3];
+  const int64_t t0 = ((int64_t)(uint32_t)wi[2]) | ((int64_t)wi[7] << 32);
+  const int64_t base = ((int64_t)(uint32_t)wi[4]) | ((int64_t)wi[5] << 32);
+  const int len = WANT_K ? wi[6] : 0;
+  const int odd = (int)(base & 1);                     // image shifted by one double when K + base is not 16-byte aligned
+  double* sK = sKbuf + odd;
+  const int nf = (n1 - n0) * NDOF;
+  const bool active = tid < nlane;                     // nlane is even: pairs are active together
+  if (!P.rec_padded) {
+    const int4* __restrict__ rp4 = (const int4*)(P.lrec2 + (t0 + (active ? tid : 0)) * LS);
+#pragma unroll
+    for (int q = 0; q < LS / 4; q++) { const int4 v = rp4[q]; rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w; }
+  }
   // (padded records: idle lanes hold a zero record, i.e. element 0 / node 0 -- a harmless gather --, so nobody waits for
   //  the descriptor's lane count either)
   // Measured on MI355X (round 3): cfg3 u-phi overwrite 4.52 -> 4.27 ms, MiehePhase 5.35 -> 5.21; with off-diagonal blocks
   // the longer live ranges spill (4.56 -> 5.74 ms) and the elastic kernel loses 2 %, so those keep the old order.
-  const bool early = FA_PAIR_EARLY_GATHER && !KEEP && PF && P.rec_padded;
-  if (early) decode_and_gather();
+  const bool early = PERS || (FA_PAIR_EARLY_GATHER && !KEEP && PF && P.rec_padded);
+  if (early && !gathered) decode_and_gather();
   if constexpr (ACC) {                                 // FA_ACCUMULATE: the image starts as the caller's K / f (stream_in16)
     if constexpr (WANT_K) {
       if ((((uintptr_t)P.K) & 15) == 0) stream_in16<kBlock>(P.K + base, sK, len, odd);
@@ -1764,6 +1779,17 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
 #ifdef FA_TRACE
   tr[7] = __builtin_readcyclecounter();
 #endif
+  // PERS: the next tile of this workgroup; its lane records are requested before the write-out of this one
+  bool has_next = false;
+  int tile_next = 0;
+  if constexpr (PERS) {
+    vb += (int)gridDim.x;
+    if (vb < vtot) {
+      const int tn0 = (vb & 7) * per + (vb >> 3);
+      if (tn0 < P.ntile2) { has_next = true; tile_next = P.tile_list ? P.tile_list[tn0] : tn0; }
+    }
+    if (has_next) load_rec_padded(tile_next);          // rec[] of this tile is dead: everything was decoded out of it
+  }
   if constexpr (WANT_K) {
     if ((((uintptr_t)P.K) & 15) == 0) stream_out16<kBlock>(P.K + base, sK, len, odd, ACC || P.overwrite);
     else stream_out<kBlock>(P.K + base, sK, len, ACC || P.overwrite);
@@ -1778,7 +1804,14 @@ __global__ __launch_bounds__(SH::BLOCK) FA_PAIR_ATTR void assemble_rows_pair(con
     out[0] = tr[0]; out[1] = tr[1]; out[2] = tr[2]; out[3] = tr[3]; out[4] = tr[6]; out[5] = tr[7]; out[6] = tr[4]; out[7] = tr[5];
   }
 #endif
-  if (PF && P.err_part != nullptr) reduce_err<kBlock>(err_acc, sErr, &P.err_part[tile]);
+  if constexpr (PERS) {
+    if (FA_PAIR_PERS_GATHER && has_next) { decode_and_gather(); gathered = true; }   // in flight while the stores drain and the image is zeroed
+  }
+  if (PF && P.err_part != nullptr) { reduce_err<kBlock>(err_acc, sErr, &P.err_part[tile]); err_acc = 0.0; }
+  if (!PERS || !has_next) break;
+  __syncthreads();                                     // every lane has read its share of the image: it may be zeroed
+  tile = tile_next;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1864,9 +1897,22 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
   } else if (path == PATH_ROWS_PAIR) {
     if constexpr (SH::NIP % 2 != 0) return -1000;
     else {
+      // persistent form (P.pair_pers workgroups), padded lane records: the overwrite GET_MATRIX0 pass of the isotropic
+      // phase-field family only.  Measured (cfg3 mesh, round 3, one workgroup per tile -> persistent): AmorPhase 4.30 -> 3.93 ms,
+      // WRITTEN pattern 3.70 -> 3.40, BourdinPhase 4.44 -> 4.18; and where it is NOT used: accumulate 5.31 -> 5.82, MiehePhase
+      // 5.12 -> 5.43, elastic 2.15 -> 2.27, micromorphic 5.05-5.79 -> 5.77-6.13, GradientDamage 6.69 -> 6.69 (the loop costs
+      // 15-45 registers -- uniform values kept live around it spill into vector registers -- which those kernels do not have)
+      const bool pers = WANT_K && !KEEP && P.pair_pers > 0 && P.rec_padded && grid > P.pair_pers;
+      const int pgrid = P.pair_pers;
       auto go = [&](auto spec) {
         using SP = decltype(spec);
         if constexpr (WANT_K && FAM == FAM_PF_ISO && !KEEP) {
+          if constexpr (!SP::gd) {
+            if (P.overwrite && pers) {
+              hipLaunchKernelGGL((assemble_rows_pair<SH, FAM, WANT_K, KEEP, SP, true, false, true>), dim3(pgrid), dim3(SH::BLOCK), 0, st, P);
+              return;
+            }
+          }
           if (P.overwrite) { hipLaunchKernelGGL((assemble_rows_pair<SH, FAM, WANT_K, KEEP, SP, true>), dim3(grid), dim3(SH::BLOCK), 0, st, P); return; }
         }
         if constexpr (WANT_K) {                          // FA_ACCUMULATE: the image starts as K, the write-out is a store stream
