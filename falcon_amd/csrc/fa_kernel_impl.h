@@ -1596,6 +1596,9 @@ __device__ __forceinline__ void swap_rec(const IpRec<SH, FAM, KEEP>& m, IpRec<SH
 #ifndef FA_PAIR_EARLY_GATHER
 #define FA_PAIR_EARLY_GATHER 1
 #endif
+#ifndef FA_PAIR_PERS_ACC
+#define FA_PAIR_PERS_ACC 0   /* accumulate through the persistent kernel: 5.75 against 5.31 ms on cfg3 */
+#endif
 #ifndef FA_PAIR_PERS_GATHER
 #define FA_PAIR_PERS_GATHER 0
 #endif
@@ -1908,7 +1911,7 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
         using SP = decltype(spec);
         if constexpr (WANT_K && FAM == FAM_PF_ISO && !KEEP) {
           if constexpr (!SP::gd) {
-            if (P.overwrite && pers) {
+            if ((P.overwrite || FA_PAIR_PERS_ACC) && pers) {
               hipLaunchKernelGGL((assemble_rows_pair<SH, FAM, WANT_K, KEEP, SP, true, false, true>), dim3(pgrid), dim3(SH::BLOCK), 0, st, P);
               return;
             }
