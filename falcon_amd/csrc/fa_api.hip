@@ -983,7 +983,8 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
                                      nb_ptr.data(), nb.data(), recw, fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0),
                                      budget, P.tile_block, row_order, ts, topt);
       if (c->tile_path) { c->ntile3 = ts.ntile; P.ntile3 = ts.ntile; P.tile_lds = ts.lds_bytes; }
-      if (c->tile_path && (dbg.pad_tnodes >= 0 ? dbg.pad_tnodes != 0 : true)) { c->tn_stride = pad_tile_nodes(ts); P.tn_stride = c->tn_stride; }
+      // (not for Hex20 Gauss2^3, the one configuration that measured slower with it: 3.57 -> 3.62 ms at 64^3)
+      if (c->tile_path && (dbg.pad_tnodes >= 0 ? dbg.pad_tnodes != 0 : p->shape != FA_HEX20_G2)) { c->tn_stride = pad_tile_nodes(ts); P.tn_stride = c->tn_stride; }
       // GET_INT_VECTOR passes keep no records, so a tile set sized for GET_MATRIX0 pays its Gauss-point redundancy for
       // nothing: measured faster than the row / cooperative kernels up to ~3 evaluations per point (Hex20 Gauss3: 5)
       c->tile_force_only = c->tile_path && (env ? true : (ts.point_redundancy < 3.0 && !big));   // big geometry: one workgroup per CU, 1.1 against 0.67 ms for Hex20
