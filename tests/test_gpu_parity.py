@@ -222,6 +222,37 @@ def test_many_workgroups(use_patch, monkeypatch):
     assert rel_rowmax_err(rp, K2, ref["K"]) < TOL
 
 
+@pytest.mark.parametrize("material,nwg", [(capi.AMOR_PHASE, 8), (capi.BOURDIN_PHASE, 24), (capi.AMOR_PHASE, 64)])
+def test_persistent_lane_pair_kernel(material, nwg, monkeypatch):
+    """FA_PAIR_PERSIST=n: the overwrite GET_MATRIX0 pass of the lane-pair kernel as n workgroups that each walk several
+    tiles (the default on meshes of >= 32 k tiles, which only the full-size tests reach): every workgroup count -- more
+    tiles than workgroups with a ragged last round, and more workgroups than a round needs -- against the oracle at 1e-12,
+    shuffled numbering, and bitwise equal to the one-workgroup-per-tile launch."""
+    import torch
+    coords, conn = meshgen.grid_quad4(97, 83)                               # 8232 nodes: ~130 tiles
+    coords = meshgen.distort(coords, conn, 0.2, 5)
+    coords, conn, _ = meshgen.shuffle_nodes(coords, conn, 5)
+    kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.05)
+    st = meshgen.smooth_state(coords, 3, l0=0.05)
+    cfg = po.make_config(po.QUAD4_G2, po.PHASE_FRACTURE, material, **kw)
+    dev = torch.device("cuda", 0)
+    out = []
+    for pers in (str(nwg), "0"):
+        monkeypatch.setenv("FA_PAIR_PERSIST", pers)
+        asm = capi.Assembler(capi.QUAD4_G2, capi.PHASE_FRACTURE, material, coords, conn, **kw)
+        K = torch.full((asm.nnz,), 3.0, dtype=torch.float64, device=dev); f = torch.full((asm.ndof,), 3.0, dtype=torch.float64, device=dev)
+        asm.assemble(torch.from_numpy(st).to(dev), K, f, flags=capi.OVERWRITE)
+        torch.cuda.synchronize()
+        out.append((K.cpu().numpy(), f.cpu().numpy(), asm.get_history(1)))
+        rp, ci = asm.pattern()
+        asm.close()
+    ref = po.assemble(cfg, coords, conn, rp, ci, st)
+    K, f, h = out[0]
+    assert rel_rowmax_err(rp, K, ref["K"]) < TOL and vec_err(f, ref["f"]) < TOL and vec_err(h, ref["hist_new"]) < TOL
+    assert np.array_equal(h, out[1][2])                                     # same arithmetic per Gauss point
+    assert rel_rowmax_err(rp, K, out[1][0]) < 1e-14                         # the order of the LDS adds is the waves' own
+
+
 @pytest.mark.parametrize("shape", [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2])
 def test_force_only(shape):
     run_both(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, want_K=False)
