@@ -77,8 +77,9 @@ def test_blocks_assembled_by_the_hip_path(case, dims, world):
     assert np.all(np.abs(Ko - Kd) <= tol)          # owner-complete rows + ghost block
 
 
-@pytest.mark.parametrize("case,dims", [("quad4", (150, 130)), ("hex8", (14, 12, 13)), ("quad4-force", (150, 130)), ("hex8-force", (14, 12, 13))])
-def test_interface_first_order_gives_the_same_result(case, dims):
+@pytest.mark.parametrize("case,dims", [("quad4", (150, 130)), ("hex8", (14, 12, 13)), ("quad4-force", (150, 130)), ("hex8-force", (14, 12, 13)),
+                                       ("quad4-persistent", (150, 130))])
+def test_interface_first_order_gives_the_same_result(case, dims, monkeypatch):
     """a pass issued as two launches -- the tiles that own an interface node first, on a side stream,
     the interior on the caller's stream (fa_set_interface, FA_PART_INTERFACE / FA_PART_INTERIOR) -- writes the same K, f_int
     and history as the one-launch pass, in overwrite and in accumulate mode; and OverlappedStep, with the middle rank of three
@@ -86,6 +87,8 @@ def test_interface_first_order_gives_the_same_result(case, dims):
     import torch
     dev = torch.device("cuda", 0)
     force = case.endswith("-force")
+    if case.endswith("-persistent"):                   # the interior launch as 16 persistent workgroups walking the tile list
+        monkeypatch.setenv("FA_PAIR_PERSIST", "16")
     shape = capi.QUAD4_G2 if case.startswith("quad4") else capi.HEX8_G2
     nd = len(dims) + 1
     kw = dict(young=210.0, poisson=0.3, gc=2.7e-3, l0=0.1, keep_off_diags=False)
