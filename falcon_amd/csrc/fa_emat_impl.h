@@ -500,12 +500,16 @@ __global__ __launch_bounds__(BLK) FA_EMAT_ATTR void assemble_emat(const Params P
 #endif
 // Instantiations a few registers above an occupancy step (Quad4 with a general tangent: 173, Triangle3 GradientDamage: 171;
 // the LDS of a tile leaves room for three waves per SIMD, 168 registers) are asked for that step: FA_FVEC_CAP.
+#ifndef FA_FVEC_CAP_GD
+#define FA_FVEC_CAP_GD 1
+#endif
 #ifndef FA_FVEC_CAP
 #define FA_FVEC_CAP 1
 #endif
 template <class SH, int FAM, class SP>
 constexpr int fvec_min_waves() {
   if (FA_FVEC_CAP && SH::RANK == 3) return 2;
+  if (FA_FVEC_CAP_GD && SH::RANK == 2 && SH::NPE == 4 && SP::gd_fixed) return 3;   // exponential1 + Mazars: 191 VGPRs
   return (FA_FVEC_CAP && SH::RANK == 2 && ((FAM == FAM_PF_MIEHE && SH::NPE == 4) || (SP::gd && SH::NPE == 3))) ? 3 : 1;
 }
 template <class SH, int FAM, class SP, int BLK>
@@ -1082,7 +1086,7 @@ static int launch_fvec_shape(const Params& P, int fam, int grid, void* stream) {
   if (fam == FAM_LE) return launch_fvec_one<SH, FAM_LE, SpecFixed<0, 0, 0>>(P, grid, st);
   if (fam == FAM_PF_ISO) {
     if (P.model == 1 && P.ptype == 0 && P.material == 1) return launch_fvec_one<SH, FAM_PF_ISO, SpecFixed<1, 0, 1>>(P, grid, st);
-    if (P.model == 7) return launch_fvec_one<SH, FAM_PF_ISO, SpecGD<SpecCanon>>(P, grid, st);
+    if (P.model == 7) return gd_dispatch<SpecCanon>(P, [&](auto spec) -> int { return launch_fvec_one<SH, FAM_PF_ISO, decltype(spec)>(P, grid, st); });
     return launch_fvec_one<SH, FAM_PF_ISO, SpecCanon>(P, grid, st);
   }
   if (fam == FAM_PF_MIEHE) {

@@ -48,6 +48,7 @@ struct Shape {
 // canonical dof numbering (the row kernels' precondition), which removes every uniform branch from the Gauss-point loop.
 struct SpecRuntime {
   static constexpr bool ma = false;                    // MicroPhaseFracture* + AmorPhase: SpecMA
+  static constexpr bool gd_fixed = false;              // GradientDamage with law and strain kind known at compile time
   static constexpr bool gd = false;                    // GradientDamage has kernels of its own (SpecGD): its constitutive
                                                        // branch (exp, acos, cos) costs every runtime-model kernel registers
   static __device__ __forceinline__ int model(const Params& P) { return P.model; }
@@ -60,7 +61,7 @@ struct SpecCanon : SpecRuntime {                       // runtime model, canonic
 };
 template <int MODEL, int PTYPE, int MAT>
 struct SpecFixed {
-  static constexpr bool gd = false, ma = false;
+  static constexpr bool gd = false, ma = false, gd_fixed = false;
   static __device__ __forceinline__ constexpr int model(const Params&) { return MODEL; }
   static __device__ __forceinline__ constexpr int ptype(const Params&) { return PTYPE; }
   static __device__ __forceinline__ constexpr int material(const Params&) { return MAT; }
@@ -68,11 +69,24 @@ struct SpecFixed {
 };
 
 // GradientDamage (model 7) on top of a runtime spec: the only instantiations that contain DamageMaterial's update
-template <class BASE>
+// SOFT / EQV >= 0: the softening law / equivalent-strain kind are compile-time constants (the eleven-way law switch and
+// the two unused strain routines drop out: Quad4 force-vector kernel 216 -> 191 VGPRs with Mazars, 128 with Energy; Hex8
+// 256 + 96 bytes of scratch -> 209).  Instantiated for exponential1 with Mazars (the material of every GradientDamage
+// input of the reference, tests/sm03 included) and with Energy; every other combination runs the runtime form (-1, -1).
+template <class BASE, int SOFT = -1, int EQV = -1>
 struct SpecGD : BASE {
-  static constexpr bool gd = true;
+  static constexpr bool gd = true, gd_fixed = (SOFT >= 0 && EQV >= 0);
   static __device__ __forceinline__ constexpr int model(const Params&) { return 7; }
+  static __device__ __forceinline__ int soft(const Params& P) { if constexpr (SOFT >= 0) return SOFT; else return P.soft; }
+  static __device__ __forceinline__ int eqv(const Params& P) { if constexpr (EQV >= 0) return EQV; else return P.eqv; }
 };
+// launch helper: go(spec) with the compile-time form where one exists
+template <class BASE, class F>
+static inline auto gd_dispatch(const Params& P, F&& go) {
+  if (P.soft == 3 && P.eqv == 1) return go(SpecGD<BASE, 3, 1>{});
+  if (P.soft == 3 && P.eqv == 0) return go(SpecGD<BASE, 3, 0>{});
+  return go(SpecGD<BASE>{});
+}
 
 // MicroPhaseFracture / Ext / ExtIt with AmorPhase (general-tangent family): the only instantiations with its split update
 template <class BASE>
@@ -472,47 +486,47 @@ __device__ __forceinline__ void Bt_vec(const double (&ga)[RANK], const double (&
 }
 
 // damageEvolution_ / getdOmegadKappa (DamageMaterial.cpp:712-855, laws :1044-1633): omega(kappa) and its derivative
-__device__ __forceinline__ void damage_law(const Params& P, const double kappa, double& omega, double& domega) {
+__device__ __forceinline__ void damage_law(const Params& P, const double kappa, double& omega, double& domega, const int gsoft) {
   omega = 0.0; domega = 0.0;
   const double Ki = P.kI, Kc = P.kC, K = kappa;
-  if (P.soft == 0) {
+  if (gsoft == 0) {
     if (K >= Ki) omega = 1.0 - Ki / K;
     domega = (K < Ki) ? 0.0 : Ki / (K * K);
-  } else if (P.soft == 1) {
+  } else if (gsoft == 1) {
     if (K >= Ki) { omega = K > Kc ? 1.0 : Kc * (K - Ki) / (K * (Kc - Ki)); if (omega == 1.0) omega = 0.999; }
     domega = (K < Kc) ? (Ki * Kc) / ((Kc - Ki) * K * K) : 0.0;
-  } else if (P.soft == 2) {
+  } else if (gsoft == 2) {
     if (K >= Ki) omega = K > Kc ? 0.999 : (K - Ki) / (Kc - Ki);
     domega = (K < Kc) ? 1.0 / (Kc - Ki) : 0.0;
-  } else if (P.soft == 3) {
+  } else if (gsoft == 3) {
     const double ex = exp(-P.sB * (K - Ki));
     if (K >= Ki) omega = 1.0 - (Ki / K) * (1.0 - P.sA + P.sA * ex);
     const double a = Ki / (K * K), b = a * K, c = P.sA * ex;
     domega = a * (1.0 - P.sA + c) + P.sB * b * c;
-  } else if (P.soft == 4) {
+  } else if (gsoft == 4) {
     const double ex = exp((Ki - K) / (Kc - Ki));
     if (K >= Ki) omega = 1.0 - (Ki / K) * ex;
     const double d = Ki / (K * K);
     domega = d * ex + d * K * ex / (Kc - Ki);
-  } else if (P.soft == 5) {                       // power (:1389-1413, :1446-1472), Kcc = Kc
+  } else if (gsoft == 5) {                       // power (:1389-1413, :1446-1472), Kcc = Kc
     const double a = Ki / K, b = 1.0 / (Kc - Ki), c = (Kc - K) * b;
     if (K >= Ki) {
       const double omegac = 1.0 - pow(Ki / Kc, P.sB) * pow((Kc - Kc) / (Kc - Ki), P.sA);
       omega = (K > Kc) ? omegac : 1.0 - pow(a, P.sB) * pow((Kc - K) / (Kc - Ki), P.sA);
     }
     domega = (K > Kc) ? 0.0 : pow(a, P.sB - 1.0) * pow(c, P.sA - 1.0) * ((a / K) * P.sB * c + a * P.sA * b);
-  } else if (P.soft == 6) {                       // hyperbolic (:1350-1380), sA = b; isTiny as in the checker
+  } else if (gsoft == 6) {                       // hyperbolic (:1350-1380), sA = b; isTiny as in the checker
     const double q = 1.0 + P.sA * (K - Ki);
     if (K >= Ki) { omega = 1.0 - 1.0 / q; if (fabs(1.0 - omega) < 2.2250738585072014e-308) omega = 0.999; }
     domega = P.sA / q / q;
-  } else if (P.soft == 7) {                       // exponential2Reg: not in the overloads GradientDamage reaches
-  } else if (P.soft == 8) {                       // expoEnergy (:1495-1523), sA = s
+  } else if (gsoft == 7) {                       // exponential2Reg: not in the overloads GradientDamage reaches
+  } else if (gsoft == 8) {                       // expoEnergy (:1495-1523), sA = s
     if (K >= Ki) {
       const double t = (K - Ki) / Kc, tem1 = pow(t, P.sA), tem2 = pow(t, P.sA - 1.0);
       omega = 1.0 - exp(-tem1);
       domega = exp(-tem1) * tem2 * P.sA / Kc;
     }
-  } else if (P.soft == 9) {                       // polynomial (:1530-1574); d from the un-normalised a, verbatim
+  } else if (gsoft == 9) {                       // polynomial (:1530-1574); d from the un-normalised a, verbatim
     if (K >= Ki) {
       const double an = (K - Ki) / (Kc - Ki);
       omega = 1.0 - (Ki / K) * (1.0 + (an * an) * (2.0 * an - 3.0));
@@ -760,8 +774,8 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
         double deq[S];                                    // getdEpsBardEps
 #pragma unroll
         for (int i = 0; i < S; i++) deq[i] = e0v[i];
-        if (P.eqv == 1) mazars_strain<RANK, S>(P, eps, eq, deq);
-        else if (P.eqv == 2) vonmises_strain<S>(P, eps, eq, deq);
+        if (SP::eqv(P) == 1) mazars_strain<RANK, S>(P, eps, eq, deq);
+        else if (SP::eqv(P) == 2) vonmises_strain<S>(P, eps, eq, deq);
         const double kappa0 = fabs(H0);
         const int load0 = (H0 < 0.0) ? 1 : 0;
         const double fl = pf - kappa0;                    // loading function (:383)
@@ -770,7 +784,7 @@ __device__ __forceinline__ void ip_material(const Params& P, int64_t ipoint, con
         else if (fl > 0.0) { kappa = pf; load = (kappa < P.kI) ? 0 : 1; }
         else               { kappa = kappa0; load = 0; }
         double omega, domega;
-        damage_law(P, kappa, omega, domega);
+        damage_law(P, kappa, omega, domega, SP::soft(P));
         const double s1 = 1.0 - omega;
         r.d0 = s1 * P.hd0; r.d1 = s1 * P.hd1; r.d3 = s1 * P.hd3;      // stiff = (1 - omega) elasticMod_ (:421)
 #pragma unroll
@@ -1926,7 +1940,7 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
       if constexpr (FAM == FAM_LE) go(SpecFixed<0, 0, 0>{});
       else if constexpr (FAM == FAM_PF_ISO) {
         if (P.model == 1 && P.ptype == 0 && P.material == 1) go(SpecFixed<1, 0, 1>{});
-        else if (P.model == 7) go(SpecGD<SpecCanon>{});
+        else if (P.model == 7) gd_dispatch<SpecCanon>(P, go);
         else go(SpecCanon{});
       } else {
         if (P.model == 1 && P.ptype == 0) go(SpecFixed<1, 0, 3>{});
@@ -1947,7 +1961,7 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
     if constexpr (FAM == FAM_LE) go(SpecFixed<0, 0, 0>{});
     else if constexpr (FAM == FAM_PF_ISO) {
       if (P.model == 1 && P.ptype == 0 && P.material == 1) go(SpecFixed<1, 0, 1>{});
-      else if (P.model == 7) go(SpecGD<SpecCanon>{});
+      else if (P.model == 7) gd_dispatch<SpecCanon>(P, go);
       else go(SpecCanon{});
     } else {
       if (P.model == 1 && P.ptype == 0) go(SpecFixed<1, 0, 3>{});

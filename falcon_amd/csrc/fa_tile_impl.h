@@ -1060,7 +1060,7 @@ __device__ __forceinline__ void gd_point_update(const Params& P, const double* _
   else if (fl > 0.0) { kappa = eq; load = (kappa < P.kI) ? 0 : 1; }
   else               { kappa = kappa0; load = 0; }
   double omega, domega;
-  damage_law(P, kappa, omega, domega);
+  damage_law(P, kappa, omega, domega, P.soft);
   const double s1 = 1.0 - omega;
   if constexpr (RANK == 2) {
     sig[0] = s1 * e0v[0]; sig[1] = s1 * e0v[1]; sig[3] = s1 * e0v[2];
@@ -1099,7 +1099,7 @@ __global__ void gd_table_kernel(const Params P, int npe, int nip, int plane_stre
       if constexpr (MODE == 1) {
         N = fabs(N);
         double omega, domega;
-        damage_law(P, fabs(P.hist_new[ipoint]), omega, domega);       // giveOmega (DamageMaterial.cpp:533-545)
+        damage_law(P, fabs(P.hist_new[ipoint]), omega, domega, P.soft);       // giveOmega (DamageMaterial.cpp:533-545)
         el[0] += N * omega;
       } else {
         const double* sc = P.strain + ipoint * (STR + 1);
@@ -1110,7 +1110,7 @@ __global__ void gd_table_kernel(const Params P, int npe, int nip, int plane_stre
           for (int c = 0; c < STR; c++) el[c] += N * sig[c];
         } else {
           double omega, domega;
-          damage_law(P, fabs(P.hist_new[ipoint]), omega, domega);
+          damage_law(P, fabs(P.hist_new[ipoint]), omega, domega, P.soft);
 #pragma unroll
           for (int c = 0; c < STR; c++) { el[c] += N * sc[c]; el[STR + c] += N * sig[c]; }
           el[2 * STR] += N * omega;
@@ -1378,8 +1378,11 @@ static int launch_tiles_shape(const Params& P, int fam, bool want_K, bool keep, 
     return want_K ? launch_tiles_one<SH, FAM_LE, true, false, SpecFixed<0, 0, 0>>(P, grid, st)
                   : launch_tiles_one<SH, FAM_LE, false, false, SpecFixed<0, 0, 0>>(P, grid, st);
   if (fam == FAM_PF_ISO && P.model == 7) {              // GradientDamage: all four blocks
-    if (!want_K) return launch_tiles_one<SH, FAM_PF_ISO, false, false, SpecGD<SpecCanon>>(P, grid, st);
-    return keep ? launch_tiles_one<SH, FAM_PF_ISO, true, true, SpecGD<SpecCanon>>(P, grid, st) : -1000;
+    return gd_dispatch<SpecCanon>(P, [&](auto spec) -> int {
+      using SPG = decltype(spec);
+      if (!want_K) return launch_tiles_one<SH, FAM_PF_ISO, false, false, SPG>(P, grid, st);
+      return keep ? launch_tiles_one<SH, FAM_PF_ISO, true, true, SPG>(P, grid, st) : -1000;
+    });
   }
   if (fam == FAM_PF_ISO && P.model == 1 && P.ptype == 0 && P.material == 1) {   // PhaseFracture, AT1 / AT2, AmorPhase folded in (cfg4)
     using SPF = SpecFixed<1, 0, 1>;
