@@ -1070,7 +1070,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
       const int nodw = fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0);
       // Hex8: 128 threads = the 125 elements around a Morton cell of 4 x 4 x 4 nodes (cfg4 at 128^3: 0.945 ms; 192 threads with
       // boxes of 5 x 5 x 4 nodes 1.01 ms, with the Morton cut 1.37 ms; the tile kernel's Gauss-point lanes 2.06 ms)
-      c->fvec.block = (dbg.fvec_blk == 128 || dbg.fvec_blk == 192 || dbg.fvec_blk == 256 || dbg.fvec_blk == 320) ? dbg.fvec_blk : (rank == 3 ? 128 : 192);
+      c->fvec.block = (dbg.fvec_blk == 128 || dbg.fvec_blk == 192 || dbg.fvec_blk == 256 || dbg.fvec_blk == 320) ? dbg.fvec_blk : ((rank == 3 || p->shape == FA_TRI3_G1) ? 128 : 192);   // Triangle3: 0.229 against 0.242 ms on 8 M elements (round 3)
       fa::TileOpts o;
       o.no_tab = true; o.no_f_image = true; o.fvec = maxval; o.own_doubles = (maxval * nd) | 1; o.own_doubles_alt = nd; o.max_el = c->fvec.block;
       o.conn_pad4 = npe <= 4; o.max_all = 2 * c->fvec.block;

@@ -1924,7 +1924,7 @@ static int launch_one(const Params& P, int path, int grid, hipStream_t st) {
       auto go = [&](auto spec) {
         using SP = decltype(spec);
         if constexpr (WANT_K && FAM == FAM_PF_ISO && !KEEP) {
-          if constexpr (!SP::gd) {
+          if constexpr (!SP::gd && SH::RANK == 2) {      // (the opt-in Hex8 lane pairs keep one workgroup per tile)
             if ((P.overwrite || FA_PAIR_PERS_ACC) && pers) {
               hipLaunchKernelGGL((assemble_rows_pair<SH, FAM, WANT_K, KEEP, SP, true, false, true>), dim3(pgrid), dim3(SH::BLOCK), 0, st, P);
               return;
