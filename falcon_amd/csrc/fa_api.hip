@@ -60,6 +60,9 @@ struct DebugOptions {
   int  tile_sort = -1;    // FA_TILE_SORT=0|1: owned nodes of a tile in Morton order | ascending node id
   int  tile_fu = -1;      // FA_TILE_FU=0|1: 3-D elastic GET_MATRIX0 passes take f_int from the pair lanes (K u) off / on
   int  tile_lanes = -1;   // FA_TILE_LANES=0|1|2|3: pair lanes sorted over the tile | by owned node | ... without cross-tile pair lanes | ... without any shared pair lanes
+  int  elem_tiles = -1;   // FA_ELEM_TILES=0|1|2: GET_INT_VECTOR passes on element tiles (fa_tiles.h) off / force-vector kernel and 3-D shapes of the tile kernel / 2-D shapes of the tile kernel too
+  int  elem_tile_el = 0;   // FA_ELEM_TILE_EL=n: elements per element tile of the tile kernel (0: default)
+  int  tile_fblock = -1;  // FA_TILE_FBLOCK=512|1024: workgroup size of those passes (3-D shapes)
   int  tile_fset = -1;    // FA_TILE_FSET=0|1|n: GET_INT_VECTOR passes of the tile kernel on tiles of their own off / on / on with <= n elements per tile
   int  tile_budget = 0;   // FA_TILE_BUDGET=n: LDS bytes the tiles are cut for (experiments; 0: per geometry)
   int  tile_big = -1;     // FA_TILE_BIG=0|1: two 512-thread workgroups per CU | one of 1024 threads
@@ -85,7 +88,7 @@ struct DebugOptions {
   static DebugOptions from_env() {
     DebugOptions o;
     auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_fu = geti("FA_TILE_FU", -1); o.tile_sort = geti("FA_TILE_SORT", -1); o.tile_split = geti("FA_TILE_SPLIT", -1); o.tile_budget = geti("FA_TILE_BUDGET", 0); o.tile_lanes = geti("FA_TILE_LANES", -1); o.tile_fset = geti("FA_TILE_FSET", -1);
+    o.tiles = geti("FA_TILES", -1); o.tile_order = geti("FA_TILE_ORDER", -1); o.tile_big = geti("FA_TILE_BIG", -1); o.tile_sym = geti("FA_TILE_SYM", -1); o.tile_fu = geti("FA_TILE_FU", -1); o.tile_sort = geti("FA_TILE_SORT", -1); o.tile_split = geti("FA_TILE_SPLIT", -1); o.tile_budget = geti("FA_TILE_BUDGET", 0); o.tile_lanes = geti("FA_TILE_LANES", -1); o.tile_fset = geti("FA_TILE_FSET", -1); o.tile_fblock = geti("FA_TILE_FBLOCK", -1); o.elem_tiles = geti("FA_ELEM_TILES", -1); o.elem_tile_el = geti("FA_ELEM_TILE_EL", 0);
     o.emat = geti("FA_EMAT", -1); o.emat_lds = geti("FA_EMAT_LDS", 0); o.emat_lpe = geti("FA_EMAT_LPE", 0);
     o.emat_lpe_f = geti("FA_EMAT_LPE_F", 0); o.fvec = geti("FA_FVEC", -1); o.fvec_blk = geti("FA_FVEC_BLK", 0); o.fvec_cell = geti("FA_FVEC_CELL", -1); o.fvec_atomic = geti("FA_FVEC_ATOMIC", -1);
     o.persist = geti("FA_PERSIST", -1); o.tile_cell = geti("FA_TILE_CELL", -1);
@@ -398,6 +401,7 @@ struct fa_ctx {
   TileDev ematK, ematF;                // element-matrix kernel (Quad4 / Triangle3)
   TileDev fvec;                        // force-vector kernel (Quad4 / Triangle3)
   TileDev tileF;                       // tile kernel, GET_INT_VECTOR passes: a tile set of its own (no Gauss-point records: larger tiles)
+  TileDev fvecU, tileU;                // the same two kernels on ELEMENT tiles (fa_tiles.h: every element in one tile, f_int by global atomics)
   bool parts_set = false;              // fa_set_interface has been called
   PartLists part_rows, part_pair, part_tiles, part_fvec, part_tileF;
   DebugOptions dbg;
@@ -416,7 +420,9 @@ extern "C" void fa_destroy(fa_ctx* c) {
                    c->ematK.tinfo, c->ematK.tnodes, c->ematK.telems, c->ematK.tconn, c->ematK.tpairs, c->ematK.tents,
                    c->ematF.tinfo, c->ematF.tnodes, c->ematF.telems, c->ematF.tconn, c->ematF.tpairs, c->ematF.tents,
                    c->fvec.tinfo, c->fvec.tnodes, c->fvec.telems, c->fvec.tconn, c->fvec.tpairs, c->fvec.tents, c->fvec.eslot, c->fvec.nval,
-                   c->tileF.tinfo, c->tileF.tnodes, c->tileF.telems, c->tileF.tconn, c->tileF.tpairs, c->tileF.tents };
+                   c->tileF.tinfo, c->tileF.tnodes, c->tileF.telems, c->tileF.tconn, c->tileF.tpairs, c->tileF.tents,
+                   c->fvecU.tinfo, c->fvecU.tnodes, c->fvecU.telems, c->fvecU.tconn, c->fvecU.tpairs, c->fvecU.tents, c->fvecU.eslot, c->fvecU.nval,
+                   c->tileU.tinfo, c->tileU.tnodes, c->tileU.telems, c->tileU.tconn, c->tileU.tpairs, c->tileU.tents };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (PartLists* pl : { &c->part_rows, &c->part_pair, &c->part_tiles, &c->part_fvec, &c->part_tileF })
     for (int k = 0; k < 2; k++) if (pl->d[k]) (void)hipFree(pl->d[k]);
@@ -1017,11 +1023,12 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE && p->model != FA_GRADIENT_DAMAGE;
     fa::TileOpts o;
     o.diag_only = true; o.order = 0; o.group = fa::tile_group(rank, c->fam);
+    const int fblock = (rank == 3 && dbg.tile_fblock == fa::kTileBlockBig) ? fa::kTileBlockBig : fa::kTileBlock;
     o.max_el = dbg.tile_fset > 1 ? dbg.tile_fset : 512;               // (element, Gauss point) lanes: a few passes of the workgroup
     c->tileF.ok = fa::build_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, n2e_ptr.data(), n2e_ent.data(),
                                   nb_ptr.data(), nb.data(), 0, fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0),
-                                  fa::kTileLds, fa::kTileBlock, false, tsT, o);
-    if (c->tileF.ok) { c->tileF.ntile = tsT.ntile; c->tileF.lds = tsT.lds_bytes; c->tileF.redundancy = tsT.point_redundancy; c->tileF.block = fa::kTileBlock; }
+                                  fa::kTileLds, fblock, false, tsT, o);
+    if (c->tileF.ok) { c->tileF.ntile = tsT.ntile; c->tileF.lds = tsT.lds_bytes; c->tileF.redundancy = tsT.point_redundancy; c->tileF.block = fblock; }
     if (c->tileF.ok && (dbg.pad_tnodes >= 0 ? dbg.pad_tnodes != 0 : true)) c->tn_strideF = pad_tile_nodes(tsT);
     if (dbg.verbose)
       fprintf(stderr, "[falcon_assemble] force-only tiles of the tile kernel: %s, %d tiles, %.1f owned nodes / %.1f elements per tile, LDS <= %d bytes, "
@@ -1105,6 +1112,46 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
                 tsV.ntile ? (double)nnode / tsV.ntile : 0.0, tsV.ntile ? (double)tsV.telems.size() / tsV.ntile : 0.0, tsV.lds_bytes, tsV.point_redundancy);
     }
   }
+  // ---- element tiles: GET_INT_VECTOR passes evaluate every Gauss point once (node tiles: Quad4 1.14, Hex8 1.95, Hex20 2.2
+  //      times) and add their f rows with global atomics.  Not for FA_DETERMINISTIC / FA_PART_* passes.  Force-vector kernel:
+  //      every shape (cfg3 1.23 -> 1.05 ms, Miehe 2.35 -> 1.83, cfg4 at 128^3 0.96 -> 0.56); tile kernel: the 3-D shapes
+  //      (Hex20 Gauss3^3 at 64^3 1.24 -> 0.68 ms; the 2-D shapes gain 0-17 % at tile sizes that differ per shape: FA_ELEM_TILES=2,
+  //      profiles/r03_batch30-32) ----
+  fa::TileSet tsU, tsTU;
+  {
+    const int want = dbg.elem_tiles >= 0 ? dbg.elem_tiles : 1;
+    const bool ext_state = pf && p->model != FA_PHASE_FRACTURE && p->model != FA_MICRO_PHASE_FRACTURE && p->model != FA_GRADIENT_DAMAGE;
+    const int nodw = fa::tile_node_doubles(rank, pf) + (ext_state ? 2 : 0);
+    if (want && nel > 0 && c->fvec.ok && !c->fvec.persistent) {
+      c->fvecU.block = c->fvec.block;
+      c->fvecU.ok = fa::build_element_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, nodw, 48 * 1024, c->fvecU.block, 0,
+                                            false, npe <= 4, tsU);
+      if (c->fvecU.ok) {
+        c->fvecU.ntile = tsU.ntile; c->fvecU.lds = c->fvecU.lds_alt = tsU.lds_bytes; c->fvecU.redundancy = 1.0; c->fvecU.lpe = maxval;
+        c->fvecU.conn_stride = tsU.conn_stride;
+        if (dbg.pad_tnodes >= 0 ? dbg.pad_tnodes != 0 : true) {
+          c->fvecU.tn_stride = pad_tile_nodes(tsU);
+          c->fvecU.te_stride = c->fvecU.tn_stride ? pad_tile_elems(tsU, (npe + 3) / 4, tsU.conn_stride) : 0;
+          if (!c->fvecU.te_stride) c->fvecU.tn_stride = 0;
+        }
+      }
+      if (dbg.verbose)
+        fprintf(stderr, "[falcon_assemble] force-vector ELEMENT tiles: %s, %d tiles of <= %d elements (%.1f nodes per tile), LDS <= %d bytes\n",
+                c->fvecU.ok ? "ok" : "not built", tsU.ntile, c->fvecU.block, tsU.ntile ? (double)tsU.tnodes.size() / tsU.ntile : 0.0, tsU.lds_bytes);
+    } else if (want && (rank == 3 || want > 1) && nel > 0 && c->tileF.ok && c->tile_force_only) {
+      c->tileU.block = c->tileF.block;
+      const int max_el = dbg.elem_tile_el > 0 ? dbg.elem_tile_el : 64;
+      c->tileU.ok = fa::build_element_tiles(nnode, nel, npe, sh.nip, rank, nd, p->coords, p->conn, nodw, fa::kTileLds, max_el, 0,
+                                            true, false, tsTU);
+      if (c->tileU.ok) {
+        c->tileU.ntile = tsTU.ntile; c->tileU.lds = tsTU.lds_bytes; c->tileU.redundancy = 1.0;
+        if (dbg.pad_tnodes >= 0 ? dbg.pad_tnodes != 0 : true) c->tileU.tn_stride = pad_tile_nodes(tsTU);
+      }
+      if (dbg.verbose)
+        fprintf(stderr, "[falcon_assemble] tile kernel, ELEMENT tiles of the force-only passes: %s, %d tiles of <= %d elements (%.1f nodes per tile), LDS <= %d bytes\n",
+                c->tileU.ok ? "ok" : "not built", tsTU.ntile, max_el, tsTU.ntile ? (double)tsTU.tnodes.size() / tsTU.ntile : 0.0, tsTU.lds_bytes);
+    }
+  }
   c->nwg = rows_ok ? (int)wg_start.size() - 1 : 0;
   c->ngrid_generic = (int)((nel * npe + kBlock - 1) / kBlock);
 
@@ -1171,6 +1218,12 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
     if ((st = upload(&c->fvec.eslot, tsV.eslot.data(), tsV.eslot.size()))) return st;
     if ((st = upload(&c->fvec.nval, tsV.nval.data(), tsV.nval.size()))) return st;
   }
+  if (c->fvecU.ok) {
+    if ((st = upload_set(c->fvecU, tsU))) return st;
+    if ((st = upload(&c->fvecU.eslot, tsU.eslot.data(), tsU.eslot.size()))) return st;
+    if ((st = upload(&c->fvecU.nval, tsU.nval.data(), tsU.nval.size()))) return st;
+  }
+  if (c->tileU.ok && (st = upload_set(c->tileU, tsTU))) return st;
   const int64_t nipt = nel * sh.nip;
   if (p->model == FA_PHASE_FRACTURE || p->model >= FA_MICRO_PHASE_FRACTURE) {
     for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void**)&c->d_hist[k], std::max<int64_t>(nipt, 1) * sizeof(double)));
@@ -1180,6 +1233,7 @@ static fa_status create_impl(const fa_problem* p, fa_ctx* c) {
   }
   c->max_parts = std::max(std::max(std::max(std::max(std::max(c->nwg, c->ntile2), c->ngrid_generic), c->npatch), c->ngrid_coop), c->ntile3);
   c->max_parts = std::max(c->max_parts, std::max(std::max(c->ematK.ntile, c->ematF.ntile), std::max(c->fvec.ntile, c->tileF.ntile)));
+  c->max_parts = std::max(c->max_parts, std::max(c->fvecU.ntile, c->tileU.ntile));
   if (p->model >= FA_MICRO_PHASE_FRACTURE && p->model <= FA_MICRO_PHASE_FRACTURE_EXTIT && p->material == FA_AMOR_PHASE) {
     HIP_TRY(hipMalloc((void**)&c->d_first_comp, sizeof(unsigned long long)));
     if (c->dbg.micro_mask) HIP_TRY(hipMalloc((void**)&c->d_comp_mask, sizeof(uint32_t) * std::max<int64_t>(nel, 1)));
@@ -1325,7 +1379,8 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   const bool keep = want_K && (P.keep2 || P.keep3);
   // bitwise reproducibility exists on the ordered row kernel only: the tile / cooperative / generic kernels add f_int
   // (and, the last two, K) with atomics whose order varies from run to run
-  const TileDev* emat = (a->flags & FA_FORCE_GENERIC) ? nullptr : (a->K_values ? ((c->ematK.ok && !c->P.k2sig) ? &c->ematK : nullptr) : (c->fvec.ok ? &c->fvec : (c->ematF.ok ? &c->ematF : nullptr)));
+  const bool elem_ok = !(a->flags & (FA_FORCE_GENERIC | FA_DETERMINISTIC | FA_PART_INTERFACE | FA_PART_INTERIOR));   // element tiles: atomic f rows, no interface lists
+  const TileDev* emat = (a->flags & FA_FORCE_GENERIC) ? nullptr : (a->K_values ? ((c->ematK.ok && !c->P.k2sig) ? &c->ematK : nullptr) : ((c->fvecU.ok && elem_ok) ? &c->fvecU : (c->fvec.ok ? &c->fvec : (c->ematF.ok ? &c->ematF : nullptr))));
   if ((a->flags & FA_DETERMINISTIC) && !emat && (!c->rows_path || (a->flags & FA_FORCE_GENERIC)))
     return fail(FA_ERR_UNSUPPORTED, "FA_DETERMINISTIC needs the row kernel (Triangle3/Gauss1, Quad4, Hex8 on a canonical node-major "
                                     "pattern): this context runs an atomic-scatter kernel");
@@ -1345,14 +1400,19 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
     P.tile_fu = 0;                                     // f_int from the Gauss-point lanes: the K u form zeroes f for the whole mesh first
   }
   const bool tile_fset = path == fa::PATH_TILES && !want_K && c->tileF.ok && !emat;
-  if (tile_fset) {                                     // GET_INT_VECTOR pass of the tile kernel: its own, larger tiles
-    P.tinfo = c->tileF.tinfo; P.tnodes = c->tileF.tnodes; P.telems = c->tileF.telems; P.tconn = c->tileF.tconn;
-    P.tpairs = c->tileF.tpairs; P.tents = c->tileF.tents; P.ntile3 = c->tileF.ntile; P.tile_lds = c->tileF.lds;
-    P.tile_block = c->tileF.block; P.tile_sym = 0; P.tile_stage = 0; P.tile_split = 0; P.tn_stride = c->tn_strideF;
+  P.f_atomic = 0;
+  const bool tile_uset = tile_fset && c->tileU.ok && elem_ok;
+  const int tf_ntile = tile_uset ? c->tileU.ntile : c->tileF.ntile;
+  if (tile_fset) {                                     // GET_INT_VECTOR pass of the tile kernel: its own, larger tiles (or element tiles)
+    const TileDev& tf = tile_uset ? c->tileU : c->tileF;
+    P.tinfo = tf.tinfo; P.tnodes = tf.tnodes; P.telems = tf.telems; P.tconn = tf.tconn;
+    P.tpairs = tf.tpairs; P.tents = tf.tents; P.ntile3 = tf.ntile; P.tile_lds = tf.lds;
+    P.tile_block = tf.block; P.tile_sym = 0; P.tile_stage = 0; P.tile_split = 0; P.tn_stride = tile_uset ? tf.tn_stride : c->tn_strideF;
+    P.f_atomic = tile_uset ? 1 : 0;
   }
   if (emat) {                                          // element-matrix kernel: no atomics, so it also serves FA_DETERMINISTIC
     P.tn_stride = emat->tn_stride; P.te_stride = emat->te_stride;
-    path = (emat == &c->fvec) ? fa::PATH_FVEC : fa::PATH_EMAT;
+    path = (emat == &c->fvec || emat == &c->fvecU) ? fa::PATH_FVEC : fa::PATH_EMAT;
     P.eslot = emat->eslot; P.nval = emat->nval; P.fvec_val = emat->lpe;
     P.tinfo = emat->tinfo; P.tnodes = emat->tnodes; P.telems = emat->telems; P.tconn = emat->tconn;
     P.tpairs = emat->tpairs; P.tents = emat->tents; P.ntile3 = emat->ntile; P.tile_lds = emat->lds;
@@ -1362,12 +1422,13 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
     // workgroup per CU) instead of ordered per-element rows: measured 1.25 against 1.27 ms on cfg3, not worth giving up the
     // repeatable sum, so it stays opt-in
     P.fvec_atomic = (emat == &c->fvec && !(a->flags & FA_DETERMINISTIC) && (c->dbg.fvec_atomic > 0) && !emat->persistent) ? 1 : 0;
+    if (emat == &c->fvecU) { P.fvec_atomic = 1; P.f_atomic = 1; }   // element tiles: one LDS row per tile node, added to f_int with global atomics
     if (P.fvec_atomic) P.tile_lds = emat->lds_alt;
     if (emat->persistent) {
       P.persistent = 1; P.st_maxn = emat->maxn; P.st_maxe = emat->maxe; P.tile_lds = emat->plds;
     }
   }
-  if (P.tile_fu && P.overwrite && c->nel > 0) HIP_TRY(hipMemsetAsync(a->f_int, 0, sizeof(double) * c->ndof, st));
+  if ((P.tile_fu || P.f_atomic) && P.overwrite && c->nel > 0) HIP_TRY(hipMemsetAsync(a->f_int, 0, sizeof(double) * c->ndof, st));
   if (c->nel == 0) {
     if (P.overwrite) {
       if (want_K) HIP_TRY(hipMemsetAsync(a->K_values, 0, sizeof(double) * c->nnz, st));
@@ -1398,7 +1459,7 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   else if (path == fa::PATH_PATCH) grid = c->npatch;
   else if (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) { P.ntile = c->nwg; grid = (c->nwg + 7) / 8 * 8; }
   else if (path == fa::PATH_ROWS_PAIR) grid = (c->ntile2 + 7) / 8 * 8;
-  else if (path == fa::PATH_TILES) grid = ((tile_fset ? c->tileF.ntile : c->ntile3) + 7) / 8 * 8;
+  else if (path == fa::PATH_TILES) grid = ((tile_fset ? tf_ntile : c->ntile3) + 7) / 8 * 8;
   else if (path == fa::PATH_EMAT || path == fa::PATH_FVEC) {
     grid = (emat->ntile + 7) / 8 * 8;
     if (emat->persistent) {                            // as many workgroups as fit the GPU at once (LDS-bound), a multiple of 8
@@ -1443,7 +1504,7 @@ static fa_status assemble_impl(fa_ctx* c, const fa_assemble_args* a, bool noallo
   if (rc == -1000) return fail(FA_ERR_UNSUPPORTED, "kernel family not built for this shape");
   if (rc != 0) return fail(FA_ERR_HIP, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
   if (want_err && part != 0) {                          // (a split pass sums its partials in the interior call: order it after the interface call)
-    const int nparts = (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) ? c->nwg : (path == fa::PATH_ROWS_PAIR ? c->ntile2 : (path == fa::PATH_TILES ? (tile_fset ? c->tileF.ntile : c->ntile3) : ((path == fa::PATH_EMAT || path == fa::PATH_FVEC) ? emat->ntile : grid)));
+    const int nparts = (path == fa::PATH_ROWS || path == fa::PATH_ROWS_ORDERED) ? c->nwg : (path == fa::PATH_ROWS_PAIR ? c->ntile2 : (path == fa::PATH_TILES ? (tile_fset ? tf_ntile : c->ntile3) : ((path == fa::PATH_EMAT || path == fa::PATH_FVEC) ? emat->ntile : grid)));
     hipLaunchKernelGGL(reduce_err_kernel, dim3(1), dim3(256), 0, st, err_part, nparts, a->err_ext);
     HIP_TRY(hipGetLastError());
   }

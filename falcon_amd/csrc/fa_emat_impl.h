@@ -847,7 +847,8 @@ __global__ __launch_bounds__(BLK, (fvec_min_waves<SH, FAM, SP>())) FA_FVEC_ATTR 
     double s = 0.0;
     for (int k = 0; k < val; k++) s += src[k * NDOF];
     const int64_t q = (int64_t)sNode[ia] * NDOF + c;
-    P.f[q] = P.overwrite ? s : P.f[q] + s;
+    if (P.f_atomic) atomicAdd(&P.f[q], s);             // element tiles (fa_tiles.h): a node's row is summed over several tiles
+    else P.f[q] = P.overwrite ? s : P.f[q] + s;
   }
   if (PF && P.err_part != nullptr) reduce_err<BLK>(err_acc, sErr, &P.err_part[tile]);
 }

@@ -162,7 +162,7 @@ struct Params {
   double*        f;
   // ---- sizes / switches ----
   int64_t nnode, nel;
-  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2, ntile3, tile_lds, tile_stage, tile_block, tile_sym, tile_split, tile_fu, fvec_atomic, rec_padded, pair_pers, tn_stride, te_stride, emat_lpe, fvec_val, conn_stride, st_maxn, st_maxe, persistent;
+  int32_t model, material, ptype, keep2, keep3, overwrite, max_valence, ndofpn, col_sorted, plds, canon, ntile, ntile2, ntile3, tile_lds, tile_stage, tile_block, tile_sym, tile_split, tile_fu, fvec_atomic, f_atomic, rec_padded, pair_pers, tn_stride, te_stride, emat_lpe, fvec_val, conn_stride, st_maxn, st_maxe, persistent;
   int32_t cnt[4];            // entries per neighbour node in a row of dof type i
   int32_t off[4][4];         // offset of column type j inside that group, -1 if not in the pattern
   // ---- constants ----

@@ -23,6 +23,16 @@
 #ifndef FA_TILE_UNROLL_IPMAJ
 #define FA_TILE_UNROLL_IPMAJ 1   /* 8 measured slower: cfg4 at 128^3 5.05 against 4.88 ms */
 #endif
+// Hex20 GET_INT_VECTOR passes, measured and left off (profiles/r03_batch29.txt, 64^3 Gauss3^3, 1.23 ms as is): point-major lanes
+// as for Hex8 (FA_TILE_IPMAJ20=1) 1.29-1.33 ms, node loops unrolled by 4 / 20 (FA_TILE_UNROLL_F20) 1.27 / 1.33 ms, workgroups
+// of 1024 (FA_TILE_FBLOCK) 1.35 ms -- the pass is bound by instruction issue (LDS reads + address arithmetic + FMAs), not by
+// latency; what halves it is evaluating every point once (element tiles, fa_tiles.h)
+#ifndef FA_TILE_IPMAJ20
+#define FA_TILE_IPMAJ20 0
+#endif
+#ifndef FA_TILE_UNROLL_F20
+#define FA_TILE_UNROLL_F20 1
+#endif
 #ifndef FA_TILE_UNROLL_A
 #define FA_TILE_UNROLL_A 1
 #endif
@@ -166,7 +176,8 @@ __global__ __launch_bounds__(BLK, (tile_min_waves<SH, FAM, BLK>())) void assembl
   // of 8 elements: the point index is wave-uniform, so the shape tables come through scalar loads instead of per-lane LDS
   // reads, and the lanes of a wave add to the f rows of different nodes (on a structured mesh local node a of different
   // elements is never the same node)
-  constexpr bool IPMAJ = (RANK == 3 && NPE == 8 && NIP == 8);
+  // (Hex20 GET_INT_VECTOR passes in the same order: FA_TILE_IPMAJ20, measured slower)
+  constexpr bool IPMAJ = RANK == 3 && ((NPE == 8 && NIP == 8) || (FA_TILE_IPMAJ20 && NPE == 20 && (!WANT_K || FA_TILE_IPMAJ20 > 1)));
   const int nel_pad = (n_el + 63) & ~63;
   const const_dptr gN = (const_dptr)P.tab, gD = gN + NIP * NPE, gW = gN + NIP * NPE * (1 + RANK);
   auto TN = [&](int idx) -> double { if constexpr (IPMAJ) return gN[idx]; else return tabN[idx]; };
@@ -196,7 +207,8 @@ __global__ __launch_bounds__(BLK, (tile_min_waves<SH, FAM, BLK>())) void assembl
       for (int k = 0; k < RANK; k++) { J[i][k] = 0.0; Fm[i][k] = 0.0; }
     }
     const bool lean = FU_CAP && fu;                      // only J is needed
-#pragma unroll (IPMAJ ? FA_TILE_UNROLL_IPMAJ : FA_TILE_UNROLL_A)
+    constexpr bool F20 = !WANT_K && NPE == 20;
+#pragma unroll (F20 ? FA_TILE_UNROLL_F20 : (IPMAJ ? FA_TILE_UNROLL_IPMAJ : FA_TILE_UNROLL_A))
     for (int a = 0; a < NPE; a++) {
       const double* nd = sNod + (int)lc[a] * NODW;
 #pragma unroll
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(BLK, (tile_min_waves<SH, FAM, BLK>())) void assembl
         }
       }
       const double wcf = PF ? w * m.cf : 0.0;
-#pragma unroll 1
+#pragma unroll (F20 ? FA_TILE_UNROLL_F20 : 1)
       for (int q = 0; q < NPE; q++) {
         int a = q + (ip % NPE); if (a >= NPE) a -= NPE;
         const int li = (int)lc[a];
@@ -443,7 +455,8 @@ __global__ __launch_bounds__(BLK, (tile_min_waves<SH, FAM, BLK>())) void assembl
     for (int i = tid; i < n_own * NDOF; i += BLK) {
       const int ia = i / NDOF;
       const int64_t q = (int64_t)P.tnodes[node_off + ia] * NDOF + (i - ia * NDOF);
-      P.f[q] = P.overwrite ? sF[i] : P.f[q] + sF[i];
+      if (P.f_atomic) atomicAdd(&P.f[q], sF[i]);       // element tiles (fa_tiles.h): a node's row is summed over several tiles
+      else P.f[q] = P.overwrite ? sF[i] : P.f[q] + sF[i];
     }
 
   // ---- phase 2: node-pair blocks of K1..K4 (PhaseFractureModel.cpp:713-722) ----

@@ -91,4 +91,15 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
                  const int32_t* nb, int rec_doubles, int node_doubles, int lds_budget, int block, bool row_order, TileSet& out,
                  const TileOpts& opts = TileOpts());
 
+// ELEMENT tiles (GET_INT_VECTOR passes of the 3-D shapes): the elements, sorted along a Morton curve of their centroids, are cut
+// into runs of at most `max_el` elements / `max_all` nodes whose nodal data fit `lds_budget`; a tile's nodes are the nodes of
+// its elements, all of them "owned" (tinfo: n_own = n_all).  Every element belongs to exactly one tile -- no Gauss point is
+// evaluated twice (the node tiles above evaluate a Hex8 point 1.95 times, a Hex20 point 2.2 times) -- and the kernels add a
+// tile's f rows to f_int with global atomics, since a node's row is then summed over several tiles.
+// with_tab: the tile kernel's layout (shape tables and row bases in LDS); otherwise the force-vector kernel's one-row-per-node
+// layout (eslot / nval are filled with zeros: that kernel's early loads read them).
+bool build_element_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndofpn, const double* coords,
+                         const int32_t* conn, int node_doubles, int lds_budget, int max_el, int max_all, bool with_tab,
+                         bool conn_pad4, TileSet& out);
+
 }  // namespace fa

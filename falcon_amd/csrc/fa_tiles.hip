@@ -507,4 +507,117 @@ bool build_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndo
   return true;
 }
 
+bool build_element_tiles(int64_t nnode, int64_t nel, int npe, int nip, int rank, int ndofpn, const double* coords,
+                         const int32_t* conn, int node_doubles, int lds_budget, int max_el, int max_all, bool with_tab,
+                         bool conn_pad4, TileSet& T) {
+  if (nnode <= 0 || nel <= 0 || npe > 255 || max_el <= 0) return false;
+  if (conn_pad4 && npe > 4) return false;
+  // ---- Morton order of the element centroids, quantised to the mean element spacing ----
+  double lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+  for (int d = 0; d < rank; d++) { lo[d] = hi[d] = coords[d]; }
+  for (int64_t n = 0; n < nnode; n++)
+    for (int d = 0; d < rank; d++) { lo[d] = std::min(lo[d], coords[n * rank + d]); hi[d] = std::max(hi[d], coords[n * rank + d]); }
+  double vol = 1.0, ext = 0.0;
+  for (int d = 0; d < rank; d++) ext = std::max(ext, hi[d] - lo[d]);
+  if (!(ext > 0.0)) return false;
+  int live = 0;
+  for (int d = 0; d < rank; d++) if (hi[d] - lo[d] > 1e-12 * ext) { vol *= hi[d] - lo[d]; live++; }
+  const double h = std::pow(vol / (double)nel, 1.0 / std::max(live, 1));
+  const uint64_t qmax = (rank == 3) ? 0x1FFFFFULL : 0x7FFFFFFFULL;
+  std::vector<uint64_t> code((size_t)nel);
+  par_for(nel, [&](int64_t b, int64_t e) {
+    for (int64_t el = b; el < e; el++) {
+      uint64_t q[3] = { 0, 0, 0 };
+      for (int d = 0; d < rank; d++) {
+        double c = 0.0;
+        for (int a = 0; a < npe; a++) c += coords[(int64_t)conn[el * npe + a] * rank + d];
+        const double v = std::floor((c / npe - lo[d]) / h);
+        q[d] = (uint64_t)std::min<double>(std::max(v, 0.0), (double)qmax);
+      }
+      code[(size_t)el] = (rank == 3) ? (spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2))
+                                     : (spread2(q[0]) | (spread2(q[1]) << 1));
+    }
+  });
+  std::vector<int32_t> order((size_t)nel);
+  for (int64_t e = 0; e < nel; e++) order[(size_t)e] = (int32_t)e;
+  std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return code[a] != code[b] ? code[a] < code[b] : a < b; });
+  code.clear(); code.shrink_to_fit();
+
+  const int cs = conn_pad4 ? 4 : npe;
+  const int64_t tabn = with_tab ? (int64_t)nip * npe * (1 + rank) + nip : 0;
+  auto bytes = [&](int64_t n_el, int64_t n_all) { return 8 * (n_all * (node_doubles + ndofpn + 2) + tabn) + 2 * n_el * cs + 16; };
+  // ---- greedy cut ----
+  std::vector<int64_t> starts;                          // first position of every tile in `order` (+ sentinel)
+  std::vector<int32_t> n_alls;
+  {
+    std::vector<int32_t> nstamp((size_t)nnode, -1);
+    int32_t cur = 0; int64_t n_el = 0, n_all = 0;
+    for (int64_t i = 0; i < nel; i++) {
+      const int32_t* cn = conn + (int64_t)order[(size_t)i] * npe;
+      for (int attempt = 0; attempt < 2; attempt++) {
+        int64_t add = 0;
+        for (int a = 0; a < npe; a++) {
+          bool seen = nstamp[cn[a]] == cur;
+          for (int b = 0; b < a && !seen; b++) seen = cn[b] == cn[a];
+          if (!seen) add++;
+        }
+        const bool fits = n_el + 1 <= max_el && (max_all <= 0 || n_all + add <= max_all) && n_all + add <= 65535 &&
+                          bytes(n_el + 1, n_all + add) <= lds_budget;
+        if (fits) {
+          if (n_el == 0) starts.push_back(i);
+          for (int a = 0; a < npe; a++) nstamp[cn[a]] = cur;
+          n_el++; n_all += add;
+          break;
+        }
+        if (n_el == 0) return false;                    // a single element does not fit
+        n_alls.push_back((int32_t)n_all); cur++; n_el = 0; n_all = 0;
+      }
+    }
+    if (n_el > 0) n_alls.push_back((int32_t)n_all);
+    starts.push_back(nel);
+  }
+  const int64_t ntile = (int64_t)starts.size() - 1;
+  if (ntile <= 0 || ntile > 0x7FFFFFF0LL || (int64_t)n_alls.size() != ntile) return false;
+  std::vector<int64_t> o_node((size_t)ntile + 1, 0);
+  int64_t max_bytes = 0;
+  for (int64_t t = 0; t < ntile; t++) {
+    const int64_t n_el = starts[(size_t)t + 1] - starts[(size_t)t];
+    o_node[t + 1] = o_node[t] + n_alls[(size_t)t];
+    max_bytes = std::max(max_bytes, bytes(n_el, n_alls[(size_t)t]));
+    T.max_all = std::max(T.max_all, n_alls[(size_t)t]); T.max_own = T.max_all; T.max_el = std::max(T.max_el, (int)n_el);
+  }
+  if (o_node[ntile] > 0x7FFFFFF0LL || nel * 4 > 0x7FFFFFF0LL) return false;
+  T.ntile = (int)ntile; T.lds_bytes = (int)max_bytes; T.lds_bytes_alt = (int)max_bytes;
+  T.conn_stride = cs; T.point_redundancy = 1.0;
+  T.tinfo.assign((size_t)ntile * kTileInfo, 0);
+  T.tnodes.assign((size_t)o_node[ntile], 0); T.telems.assign((size_t)nel, 0);
+  T.tconn.assign((size_t)nel * cs, 0);
+  T.tpairs.assign(4, 0); T.tents.assign(1, 0);
+  if (!with_tab) { T.eslot.assign((size_t)nel * ((npe + 3) / 4), 0); T.nval.assign((size_t)o_node[ntile], 0); }
+  par_for(ntile, [&](int64_t tb, int64_t te) {
+    std::vector<int32_t> nodes;
+    for (int64_t t = tb; t < te; t++) {
+      const int64_t e0 = starts[(size_t)t], n_el = starts[(size_t)t + 1] - e0;
+      nodes.clear();
+      for (int64_t s = 0; s < n_el; s++)
+        for (int a = 0; a < npe; a++) nodes.push_back(conn[(int64_t)order[(size_t)(e0 + s)] * npe + a]);
+      std::sort(nodes.begin(), nodes.end()); nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+      const int n_all = (int)nodes.size();                 // == n_alls[t]
+      int32_t* ti = T.tinfo.data() + t * kTileInfo;
+      ti[0] = (int32_t)o_node[t]; ti[1] = n_all; ti[2] = n_all; ti[3] = (int32_t)e0; ti[4] = (int32_t)n_el;
+      std::copy(nodes.begin(), nodes.end(), T.tnodes.begin() + o_node[t]);
+      // the elements of a tile in ascending id (like the node tiles): on meshes numbered row by row neighbouring lanes then
+      // read neighbouring history values
+      std::sort(order.begin() + e0, order.begin() + e0 + n_el);
+      for (int64_t s = 0; s < n_el; s++) {
+        const int32_t el = order[(size_t)(e0 + s)];
+        T.telems[(size_t)(e0 + s)] = el | (int32_t)0x80000000;     // the one tile of the element stores its per-point outputs
+        for (int a = 0; a < npe; a++)
+          T.tconn[(size_t)(e0 + s) * cs + a] = (uint16_t)(std::lower_bound(nodes.begin(), nodes.end(), conn[(int64_t)el * npe + a]) - nodes.begin());
+      }
+    }
+  });
+  return true;
+}
+
 }  // namespace fa

@@ -111,7 +111,9 @@ enum {
                            Triangle3/Gauss1, Quad4 and Hex8 on the canonical node-major pattern only: on every other
                            context (higher-order shapes, a custom dof map or pattern) the call is refused with
                            FA_ERR_UNSUPPORTED -- those kernels add f_int (and, for non-canonical patterns, K) with
-                           atomics whose order varies from run to run */
+                           atomics whose order varies from run to run.  Without the flag a GET_INT_VECTOR pass of these
+                           shapes runs on ELEMENT tiles (every Gauss point evaluated once, f_int rows added with global
+                           atomics: 14-49 % faster, equal to the ordered sum to rounding, ~1e-16 relative) */
 };
 
 typedef struct {

@@ -59,9 +59,11 @@ def test_emat_many_tiles_and_bitwise_repeatability(shape, mesh, shuffle, emat):
     assert vec_err(asm.get_history(1), ref["hist_new"]) < TOL
     K2, f2, _ = asm.assemble_host(st, np.zeros(asm.nnz), flags=capi.OVERWRITE | capi.DETERMINISTIC)
     assert np.array_equal(K, K2) and np.array_equal(f, f2)          # no atomics anywhere: every run gives the same bits
-    _, f3, _ = asm.assemble_host(st, None, np.zeros(asm.ndof), flags=capi.OVERWRITE)
+    _, f3, _ = asm.assemble_host(st, None, np.zeros(asm.ndof), flags=capi.OVERWRITE)     # default: element tiles, atomic f rows
     assert vec_err(f3, ref["f"]) < TOL
-    _, f4, _ = asm.assemble_host(st, None, np.zeros(asm.ndof), flags=capi.OVERWRITE)
+    _, f3, _ = asm.assemble_host(st, None, np.zeros(asm.ndof), flags=capi.OVERWRITE | capi.DETERMINISTIC)
+    assert vec_err(f3, ref["f"]) < TOL
+    _, f4, _ = asm.assemble_host(st, None, np.zeros(asm.ndof), flags=capi.OVERWRITE | capi.DETERMINISTIC)
     assert np.array_equal(f3, f4)
 
 

@@ -89,10 +89,28 @@ def test_tile_kernel_parity_on_many_tiles(case):
     # the GET_INT_VECTOR pass (Hex8: the force-vector kernel) rewrites newHist_ as well, and repeats bit for bit
     if hist is not None:
         assert np.abs(asm.get_history(1) - ref["hist_new"]).max() < 1e-12 * max(1.0, np.abs(ref["hist_new"]).max())
+    # += semantics of a GET_INT_VECTOR pass (3-D shapes: element tiles, f rows added with global atomics)
+    f6 = torch.full_like(f, 1.0)
+    asm.assemble(t(st), None, f6, flags=capi.ACCUMULATE, **args)
+    assert (f6 - 1.0 - f).abs().max().item() < 1e-12 * fmax
     if shape == capi.HEX8_G2 and os.environ.get("FA_FVEC") != "0":   # (FA_FVEC=0: f4 came from the tile kernel's LDS atomics)
-        f5 = torch.zeros_like(f)
+        # FA_DETERMINISTIC: the force-vector kernel on node tiles, ordered sums -- repeats bit for bit; the default pass runs
+        # on element tiles (atomic adds) unless FA_ELEM_TILES=0
+        f5 = torch.zeros_like(f); f7 = torch.full_like(f, 3.0)
         asm.assemble(t(st), None, f5, flags=capi.OVERWRITE | capi.DETERMINISTIC, **args)
-        assert torch.equal(f4, f5)
+        asm.assemble(t(st), None, f7, flags=capi.OVERWRITE | capi.DETERMINISTIC, **args)
+        assert torch.equal(f5, f7)
+        assert (f5 - f).abs().max().item() < 1e-12 * fmax
+        if os.environ.get("FA_ELEM_TILES") == "0":
+            assert torch.equal(f4, f5)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4])
+def test_force_only_on_node_tiles(case, monkeypatch):
+    """FA_ELEM_TILES=0: the GET_INT_VECTOR passes of the 3-D shapes on node tiles (what FA_DETERMINISTIC and FA_PART_* passes
+    run on); the default is element tiles (fa_tiles.h)."""
+    monkeypatch.setenv("FA_ELEM_TILES", "0")
+    test_tile_kernel_parity_on_many_tiles(case)
 
 
 @pytest.mark.parametrize("case", [0, 1])
