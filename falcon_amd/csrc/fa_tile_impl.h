@@ -27,6 +27,11 @@
 // as for Hex8 (FA_TILE_IPMAJ20=1) 1.29-1.33 ms, node loops unrolled by 4 / 20 (FA_TILE_UNROLL_F20) 1.27 / 1.33 ms, workgroups
 // of 1024 (FA_TILE_FBLOCK) 1.35 ms -- the pass is bound by instruction issue (LDS reads + address arithmetic + FMAs), not by
 // latency; what halves it is evaluating every point once (element tiles, fa_tiles.h)
+// FA_TILE_ACC_ATOMIC=1: K += of the ACC variants as atomic adds without return instead of load + add + store.  Measured
+// (profiles/r03_batch34.txt): cfg4 at 128^3 40.3 against 8.3 ms -- 16 G scattered f64 atomics a second is all the L2s give.
+#ifndef FA_TILE_ACC_ATOMIC
+#define FA_TILE_ACC_ATOMIC 0
+#endif
 #ifndef FA_TILE_IPMAJ20
 #define FA_TILE_IPMAJ20 0
 #endif
@@ -825,7 +830,13 @@ __global__ __launch_bounds__(BLK, (tile_min_waves<SH, FAM, BLK>())) void assembl
       if (NDOF == 4 && P.cnt[0] == 4 && P.cnt[3] == 4 && (reinterpret_cast<uintptr_t>(P.K) & 15) == 0) {
         if constexpr (NDOF == 4) {
           const long long b0 = sRow[io] + (long long)kp * 4, rs = (long long)sDeg[io] * 4;
-          if constexpr (ACC) {                           // the four row chunks' old values in flight together
+          if constexpr (ACC && FA_TILE_ACC_ATOMIC) {     // K += as 16 atomic adds without return: the L2 does the read-modify-write,
+                                                         // the lane waits for nothing (every entry still has one writer)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+              for (int j = 0; j < 4; j++) atomicAdd(P.K + b0 + i * rs + j, blk[i][j]);
+          } else if constexpr (ACC) {                    // the four row chunks' old values in flight together
             double2 o0[4], o1[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) { const double2* q = reinterpret_cast<const double2*>(P.K + b0 + i * rs); o0[i] = q[0]; o1[i] = q[1]; }

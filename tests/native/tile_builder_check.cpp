@@ -1,5 +1,5 @@
 // Host-side check of the tile builder (falcon_amd/csrc/fa_tiles.hip, compiled as plain C++ by tests/test_tile_builder.py).
-// usage: tile_builder_check RANK N ROW_ORDER REC_DOUBLES BIG   -> prints "key value" lines, exit code 0 when every invariant holds
+// usage: tile_builder_check RANK N ROW_ORDER REC_DOUBLES BIG [MAX_EL: element tiles]   -> prints "key value" lines, exit code 0 when every invariant holds
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -44,6 +44,39 @@ int main(int argc, char** argv) {
     for (int32_t k = n2e_ptr[q]; k < n2e_ptr[q + 1]; k++) { const int32_t* c = &conn[(int64_t)(n2e_ent[k] / npe) * npe]; t.insert(t.end(), c, c + npe); }
     std::sort(t.begin(), t.end()); t.erase(std::unique(t.begin(), t.end()), t.end());
     nb.insert(nb.end(), t.begin(), t.end()); nb_ptr[q + 1] = (int64_t)nb.size();
+  }
+  if (argc > 6 && atoi(argv[6]) > 0) {
+    // ELEMENT tiles (build_element_tiles): every element in exactly one tile, all its nodes in that tile's list, ascending
+    // element order inside a tile, limits respected
+    const int max_el = atoi(argv[6]);
+    fa::TileSet U;
+    const bool oku = fa::build_element_tiles(nn, nel, npe, nip, rank, nd, x.data(), conn.data(), fa::tile_node_doubles(rank, true), budget,
+                                             max_el, 0, !row_order, false, U);
+    printf("built %d\n", oku ? 1 : 0);
+    if (!oku) return 2;
+    std::vector<int> eseen(nel, 0);
+    int64_t bad = 0, tnodes = 0;
+    for (int t = 0; t < U.ntile; t++) {
+      const int32_t* ti = &U.tinfo[(size_t)t * fa::kTileInfo];
+      if (ti[2] != ti[1] || ti[4] > max_el || ti[4] <= 0) bad++;
+      tnodes += ti[1];
+      for (int i = 1; i < ti[1]; i++) if (U.tnodes[ti[0] + i - 1] >= U.tnodes[ti[0] + i]) bad++;       // distinct, ascending
+      for (int s = 0; s < ti[4]; s++) {
+        const uint32_t w = (uint32_t)U.telems[ti[3] + s]; const int32_t el = (int32_t)(w & 0x7fffffff);
+        if (!(w >> 31)) bad++;
+        eseen[el]++;
+        if (s > 0 && (int32_t)(U.telems[ti[3] + s - 1] & 0x7fffffff) >= el) bad++;
+        for (int a = 0; a < npe; a++) {
+          const int li = U.tconn[((size_t)ti[3] + s) * U.conn_stride + a];
+          if (li >= ti[1] || U.tnodes[ti[0] + li] != conn[(int64_t)el * npe + a]) bad++;
+        }
+      }
+    }
+    int64_t once = 0;
+    for (int v : eseen) once += (v == 1);
+    printf("ntile %d\nlds_bytes %d\nlds_budget %d\nredundancy %.4f\nelements %lld\nelements_once %lld\nbad %lld\nnodes_per_tile %.2f\n",
+           U.ntile, U.lds_bytes, budget, U.point_redundancy, (long long)nel, (long long)once, (long long)bad, (double)tnodes / U.ntile);
+    return (once == nel && bad == 0 && U.lds_bytes <= budget) ? 0 : 1;
   }
   fa::TileSet T;
   const bool ok = fa::build_tiles(nn, nel, npe, nip, rank, nd, x.data(), conn.data(), n2e_ptr.data(), n2e_ent.data(), nb_ptr.data(),

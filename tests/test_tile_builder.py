@@ -53,3 +53,15 @@ def test_large_records_shrink_the_tiles_but_stay_valid(checker):
     w = run(checker, 3, 16, 0, 120, 1)       # the same in the whole-LDS geometry: larger tiles, fewer evaluations per point
     assert w["bad"] == 0 and w["blocks_written_once"] == w["blocks"] and w["lds_bytes"] <= w["lds_budget"]
     assert w["redundancy"] < v["redundancy"] and w["lds_budget"] > v["lds_budget"]
+
+
+@pytest.mark.parametrize("rank,n,max_el", [(3, 13, 128), (3, 32, 64), (2, 50, 192), (2, 257, 128)])
+@pytest.mark.parametrize("fvec_layout", [0, 1])
+def test_element_tiles_hold_every_element_once(checker, rank, n, max_el, fvec_layout):
+    """build_element_tiles (GET_INT_VECTOR passes): a partition of the elements, every tile lists all nodes of its elements."""
+    rec = 16
+    v = run(checker, rank, n, fvec_layout, rec, 0, max_el)
+    assert v["elements_once"] == v["elements"] and v["bad"] == 0 and v["redundancy"] == 1.0
+    assert v["lds_bytes"] <= v["lds_budget"]
+    # compact runs of the Morton curve: far fewer nodes than max_el * npe
+    assert v["nodes_per_tile"] < (0.35 if rank == 3 else 0.45) * max_el * (8 if rank == 3 else 4)
