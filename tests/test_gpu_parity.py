@@ -260,6 +260,18 @@ def test_force_only(shape):
 
 
 @pytest.mark.parametrize("shape", [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2])
+@pytest.mark.parametrize("mode", ["node_tiles", "deterministic"])
+def test_force_only_on_node_tiles(shape, mode, monkeypatch):
+    """GET_INT_VECTOR passes run on element tiles by default (atomic f rows); FA_ELEM_TILES=0 and FA_DETERMINISTIC keep the
+    force-vector kernel on node tiles (ordered sums) -- what FA_PART_* passes run on as well."""
+    if mode == "node_tiles":
+        monkeypatch.setenv("FA_ELEM_TILES", "0")
+    extra = capi.DETERMINISTIC if mode == "deterministic" else 0
+    run_both(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, want_K=False, flags=capi.OVERWRITE | extra)
+    run_both(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, want_K=False, flags=capi.ACCUMULATE | extra)
+
+
+@pytest.mark.parametrize("shape", [capi.TRI3_G1, capi.QUAD4_G2, capi.HEX8_G2])
 @pytest.mark.parametrize("flags", [capi.OVERWRITE, capi.ACCUMULATE])
 def test_generic_kernel_on_canonical_pattern(shape, flags):
     run_both(shape, capi.PHASE_FRACTURE, capi.AMOR_PHASE, keep=1, flags=flags | capi.FORCE_GENERIC)
