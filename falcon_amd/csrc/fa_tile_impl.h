@@ -27,6 +27,9 @@
 // as for Hex8 (FA_TILE_IPMAJ20=1) 1.29-1.33 ms, node loops unrolled by 4 / 20 (FA_TILE_UNROLL_F20) 1.27 / 1.33 ms, workgroups
 // of 1024 (FA_TILE_FBLOCK) 1.35 ms -- the pass is bound by instruction issue (LDS reads + address arithmetic + FMAs), not by
 // latency; what halves it is evaluating every point once (element tiles, fa_tiles.h)
+#ifndef FA_TILE_ACC_TOUCH
+#define FA_TILE_ACC_TOUCH 1
+#endif
 // FA_TILE_ACC_ATOMIC=1: K += of the ACC variants as atomic adds without return instead of load + add + store.  Measured
 // (profiles/r03_batch34.txt): cfg4 at 128^3 40.3 against 8.3 ms -- 16 G scattered f64 atomics a second is all the L2s give.
 #ifndef FA_TILE_ACC_ATOMIC
@@ -75,6 +78,16 @@ template <class SH, int FAM, int BLK>
 constexpr int tile_min_waves() {
   return (FA_TILE_CAP && BLK == 512 && SH::RANK == 2 && FAM == FAM_PF_MIEHE) ? 4 : 1;
 }
+// global_load_lds_dword with a per-lane source address: 4 bytes per lane land at `lds_wave_base` + lane x 4 (wave-uniform base
+// through M0, saved and restored inside the statement); issued as inline asm so that the compiler keeps no book on it (see
+// glds in fa_emat_impl.h).  Used to pull the cache lines of a later read-modify-write into the L2 without a register.
+typedef __attribute__((address_space(3))) char* tile_lds_cptr;
+__device__ __forceinline__ void l2_touch(const void* src, void* lds_wave_base) {
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(tile_lds_cptr)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
 template <class SH, int FAM, bool WANT_K, bool KEEP, class SP, int BLK, bool ACC = false>
 __global__ __launch_bounds__(BLK, (tile_min_waves<SH, FAM, BLK>())) void assemble_tiles(const Params P) {
   constexpr int RANK = SH::RANK, NPE = SH::NPE, NIP = SH::NIP, S = SH::S, STR = SH::STR;
@@ -643,6 +656,27 @@ __global__ __launch_bounds__(BLK, (tile_min_waves<SH, FAM, BLK>())) void assembl
       Kup[i] = 0.0; Kpu[i] = 0.0; Kup2[i] = 0.0; Kpu2[i] = 0.0;
 #pragma unroll
       for (int j = 0; j < RANK; j++) Kuu[i][j] = 0.0;
+    }
+    // FA_ACCUMULATE (ACC), 4 x 4 blocks: the row chunks this lane is going to read-modify-write are requested now, through
+    // LDS-DMA loads of 4 bytes each into a dead part of the LDS (the staged nodal data: phase 1 is over) -- no registers, and
+    // nothing waits for them.  The element loop runs while the lines travel from HBM into the L2; the old values are then
+    // read from there (cfg4 at 128^3 8.25 -> 7.81 ms, at 200^3 30.8 -> 29.5, keepOffDiags 10.2 -> 9.7: profiles/r03_batch38.txt;
+    // requesting both blocks' old values together at the end on top of it costs 14 registers = a workgroup per CU: 7.97).
+    if constexpr (FA_TILE_ACC_TOUCH && ACC && PF && RANK == 3) {
+      const bool leader0 = !P.tile_split || ((pw.z >> 26) & 3u) == 0;
+      if (active && leader0 && !P.tile_stage && n_all * NODW * 8 >= (BLK / 64) * 256 && P.cnt[0] == 4 && P.cnt[3] == 4) {
+        char* sink = reinterpret_cast<char*>(sNod) + (tid >> 6) * 256;
+        const double* q0 = P.K + sRow[ia] + (long long)kpos * 4;
+        const long long rs = (long long)sDeg[ia] * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) l2_touch(q0 + i * rs, sink);
+        if (mirror) {
+          const double* q1 = P.K + sRow[ib] + (long long)kpos2 * 4;
+          const long long rs2 = (long long)sDeg[ib] * 4;
+#pragma unroll
+          for (int i = 0; i < 4; i++) l2_touch(q1 + i * rs2, sink);
+        }
+      }
     }
     uint32_t ent_next = pw.w;                            // the first entry travels in the pair record
 #pragma unroll 1
