@@ -505,9 +505,6 @@ __global__ __launch_bounds__(BLK, (tile_min_waves<SH, FAM, BLK>())) void assembl
       pw_next = (p + BLK < n_pairs) ? prec[p + BLK] : make_uint4(0u, 0u, 0u, 0u);
       const int ia = (int)(pw.x & 0xFFFFu), nb = (int)((pw.x >> 16) & 0xFFu), cnt = (int)(pw.x >> 24);
       const uint32_t* __restrict__ ents = P.tents + (int64_t)ent_off + pw.y;
-      uint32_t bw[GRP];
-#pragma unroll
-      for (int j = 0; j < GRP; j++) bw[j] = (j < nb) ? ents[j] : 0u;
       double M[GRP][3][3];
 #pragma unroll
       for (int j = 0; j < GRP; j++)
@@ -576,6 +573,11 @@ __global__ __launch_bounds__(BLK, (tile_min_waves<SH, FAM, BLK>())) void assembl
       }
       if (!active || ((pw.z >> 26) & 3u) != 0) continue;
       const bool diag = (pw.z >> 30) & 1u;
+      // the neighbour words are read here, not in front of the element loop: four registers less across it (scratch of the
+      // 1024-thread Gauss3^3 kernel 20 -> 12 bytes, cfg5 35.7 -> 34.8 ms: profiles/r03_batch39.txt)
+      uint32_t bw[GRP];
+#pragma unroll
+      for (int j = 0; j < GRP; j++) bw[j] = (j < nb) ? ents[j] : 0u;
 #pragma unroll
       for (int j = 0; j < GRP; j++) {
         if (j >= nb) continue;
